@@ -1,0 +1,20 @@
+"""imagetransformations_amd — MI355X-native (gfx950, hand-written HIP) implementation of the
+per-pixel transform hot path of aaryaamoharir/ImageTransformations.
+
+    from imagetransformations_amd import transformation as T   # drop-in apply_* functions
+    from imagetransformations_amd import ops                    # batched device-tensor API
+
+Importing the package loads libimgxf.so through ctypes and raises ImportError if it has
+not been built (`python -m imagetransformations_amd.build`).  There is no CPU fallback.
+"""
+from . import _ffi  # noqa: F401  (fails loudly when the HIP library is missing)
+
+__version__ = "0.1.0"
+__all__ = ["ops", "transformation", "sharding", "_ffi"]
+
+
+def __getattr__(name):
+    if name in ("ops", "transformation", "sharding", "pool"):
+        import importlib
+        return importlib.import_module(f"{__name__}.{name}")
+    raise AttributeError(name)

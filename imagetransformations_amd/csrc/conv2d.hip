@@ -1,0 +1,144 @@
+// Dense k x k correlation and the Sobel family.  Bodies behind
+//   cv2.filter2D(img,-1,kernel)        /root/reference/pipenline/cifar_image_transformations.py:118
+//   scipy.ndimage.sobel(gray_u8)       /root/reference/transformation.py:339
+//   benchmark configs[2] (RGB -> L -> Gx,Gy -> |G|), SURVEY §8a row a4
+// conv2d: one workgroup stages a (16+kh-1) x (128+(kw-1)*C) byte tile (+halo, border
+// resolved while loading) into LDS as fp32, each lane then owns one byte column x 8 rows.
+// sobel:  LDS-staged L tile (the RGB->L conversion is fused into the tile load for the
+// benchmark variant), exact int32 gradients.
+#include "imgxf_common.h"
+#include <string.h>
+
+namespace imgxf {
+
+struct KernelTaps { float w[15 * 15]; };
+
+__global__ __launch_bounds__(256) void conv2d_kernel(View s, View d, KernelTaps K, int kh, int kw,
+                                                     int border) {
+    constexpr int TWB = 128, TH = 16;
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int C = s.c;
+    const int ay = kh / 2, ax = kw / 2;
+    const int tw = TWB + (kw - 1) * C;   // tile width in bytes
+    const int th = TH + kh - 1;
+    const int x0b = blockIdx.x * TWB, y0 = blockIdx.y * TH, f = blockIdx.z;
+    const int rowbytes = s.w * C;
+    for (int t = threadIdx.x; t < tw * th; t += 256) {
+        const int ty = t / tw, tx = t - ty * tw;
+        int gy = y0 - ay + ty;
+        if (gy < 0 || gy >= s.h) gy = border_index(gy, s.h, border);
+        const int bx = x0b - ax * C + tx;
+        int px = bx >= 0 ? bx / C : -((-bx + C - 1) / C);
+        const int ch = bx - px * C;
+        if (px < 0 || px >= s.w) px = border_index(px, s.w, border);
+        tile[t] = (float)s.row(f, gy)[px * C + ch];
+    }
+    __syncthreads();
+    const int col = threadIdx.x & 127, rg = threadIdx.x >> 7;   // 2 row groups of 8 rows
+    const int xb = x0b + col;
+    if (xb >= rowbytes) return;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    for (int j = 0; j < kh; ++j) {
+        for (int i = 0; i < kw; ++i) {
+            const float wgt = K.w[j * kw + i];
+            const float* tp = &tile[(rg * 8 + j) * tw + col + i * C];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) acc[o] = fmaf(wgt, tp[o * tw], acc[o]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const int y = y0 + rg * 8 + o;
+        if (y < s.h) d.row(f, y)[xb] = (u8)sat_u8_rne(acc[o]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Sobel.  Tile: 64 x 16 output pixels; LDS holds the (64+2) x (16+2) L tile.
+// FROM_RGB: the tile loader converts RGB -> L with Pillow's fixed-point weights.
+// ---------------------------------------------------------------------------------------
+template <bool FROM_RGB>
+__global__ __launch_bounds__(256) void sobel_kernel(View s, View d, int variant) {
+    constexpr int TW = 64, THS = 16;
+    __shared__ int L[(THS + 2) * (TW + 2)];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * THS, f = blockIdx.z;
+    for (int t = threadIdx.x; t < (THS + 2) * (TW + 2); t += 256) {
+        const int ty = t / (TW + 2), tx = t - ty * (TW + 2);
+        int gy = y0 - 1 + ty, gx = x0 - 1 + tx;
+        if (gy < 0 || gy >= s.h) gy = reflect_sym(gy, s.h);
+        if (gx < 0 || gx >= s.w) gx = reflect_sym(gx, s.w);
+        const u8* p = s.row(f, gy) + gx * s.c;
+        int v;
+        if (FROM_RGB) v = (int)(((u32)p[0] * 19595u + (u32)p[1] * 38470u + (u32)p[2] * 7471u + 0x8000u) >> 16);
+        else v = p[0];
+        L[t] = v;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, lg = threadIdx.x >> 6;
+    const int x = x0 + lx;
+    if (x >= s.w) return;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int ly = lg * 4 + o, y = y0 + ly;
+        if (y >= s.h) break;
+        const int* c = &L[(ly + 1) * (TW + 2) + lx + 1];
+        const int a00 = c[-(TW + 2) - 1], a01 = c[-(TW + 2)], a02 = c[-(TW + 2) + 1];
+        const int a10 = c[-1], a12 = c[1];
+        const int a20 = c[(TW + 2) - 1], a21 = c[(TW + 2)], a22 = c[(TW + 2) + 1];
+        const int gx = (a02 - a00) + 2 * (a12 - a10) + (a22 - a20);
+        const int gy = (a20 - a00) + 2 * (a21 - a01) + (a22 - a02);
+        u32 out;
+        if (variant == IMGXF_SOBEL_X_WRAP) out = (u32)gx & 0xffu;
+        else if (variant == IMGXF_SOBEL_Y_WRAP) out = (u32)gy & 0xffu;
+        else out = sat_u8_rne(__fsqrt_rn((float)(gx * gx + gy * gy)));
+        d.row(f, y)[x] = (u8)out;
+    }
+}
+
+} // namespace imgxf
+
+using namespace imgxf;
+
+IMGXF_API int imgxf_conv2d_u8(const imgxf_view* src, const imgxf_view* dst, const float* kernel,
+                              int kh, int kw, int border, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    if (!kernel) return IMGXF_ERR_NULL;
+    if (!same_geometry(src, dst)) return IMGXF_ERR_SHAPE;
+    if (kh < 1 || kw < 1 || !(kh & 1) || !(kw & 1) || kh > 15 || kw > 15) return IMGXF_ERR_ARG;
+    if (border != IMGXF_BORDER_REFLECT_101 && border != IMGXF_BORDER_REFLECT) return IMGXF_ERR_ARG;
+    if (empty_view(src)) return IMGXF_OK;
+    KernelTaps K; memset(&K, 0, sizeof(K));
+    for (int i = 0; i < kh * kw; ++i) K.w[i] = kernel[i];
+    const View s = make_view(src), d = make_view(dst);
+    const size_t lds = sizeof(float) * (size_t)(128 + (kw - 1) * s.c) * (16 + kh - 1);
+    dim3 grid((unsigned)((s.rowbytes() + 127) / 128), (unsigned)((s.h + 15) / 16), (unsigned)s.n);
+    hipLaunchKernelGGL(conv2d_kernel, grid, dim3(256), lds, (hipStream_t)stream, s, d, K, kh, kw, border);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_sobel_u8(const imgxf_view* src, const imgxf_view* dst, int variant, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    if (!same_geometry(src, dst) || src->c != 1) return IMGXF_ERR_SHAPE;
+    if (variant < 0 || variant > 2) return IMGXF_ERR_ARG;
+    if (empty_view(src)) return IMGXF_OK;
+    const View s = make_view(src), d = make_view(dst);
+    dim3 grid((unsigned)((s.w + 63) / 64), (unsigned)((s.h + 15) / 16), (unsigned)s.n);
+    hipLaunchKernelGGL((sobel_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, s, d, variant);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_rgb_sobel_mag_u8(const imgxf_view* src, const imgxf_view* dst, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    if (!same_nhw(src, dst) || src->c != 3 || dst->c != 1) return IMGXF_ERR_SHAPE;
+    if (empty_view(src)) return IMGXF_OK;
+    const View s = make_view(src), d = make_view(dst);
+    dim3 grid((unsigned)((s.w + 63) / 64), (unsigned)((s.h + 15) / 16), (unsigned)s.n);
+    hipLaunchKernelGGL((sobel_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, s, d,
+                       (int)IMGXF_SOBEL_MAGNITUDE);
+    return launch_status();
+}

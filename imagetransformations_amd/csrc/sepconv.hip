@@ -1,0 +1,67 @@
+// C-ABI entry points for the separable filters (Gaussian blur).
+// Replaces cv2.GaussianBlur at /root/reference/transformation.py:249.
+#include "sepconv_tile.inc"
+#include <math.h>
+#include <string.h>
+
+namespace imgxf {
+int sepconv_tile_c1(int R, const View&, const View&, const View&, const Taps&, int, hipStream_t);
+int sepconv_tile_c3(int R, const View&, const View&, const View&, const Taps&, int, hipStream_t);
+int sepconv_tile_c4(int R, const View&, const View&, const View&, const Taps&, int, hipStream_t);
+
+static int run_sepconv(const imgxf_view* src, const imgxf_view* dst, const float* kx, int nkx,
+                       const float* ky, int nky, int border, const imgxf_view* dst_f32,
+                       void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    if (!kx || !ky) return IMGXF_ERR_NULL;
+    if (!same_geometry(src, dst)) return IMGXF_ERR_SHAPE;
+    if (nkx < 1 || nky < 1 || !(nkx & 1) || !(nky & 1) || nkx > 31 || nky > 31) return IMGXF_ERR_ARG;
+    if (border != IMGXF_BORDER_REFLECT_101 && border != IMGXF_BORDER_REFLECT) return IMGXF_ERR_ARG;
+    View df; memset(&df, 0, sizeof(df));
+    if (dst_f32) {
+        IMGXF_CHECK(check_view(dst_f32, 4));
+        if (!same_geometry(src, dst_f32)) return IMGXF_ERR_SHAPE;
+        if (((uintptr_t)dst_f32->data & 3) || (dst_f32->row_stride & 3) || (dst_f32->frame_stride & 3))
+            return IMGXF_ERR_ARG;
+        df = make_view(dst_f32);
+    }
+    if (empty_view(src)) return IMGXF_OK;
+    int R = (nkx > nky ? nkx : nky) / 2;
+    if (R < 1) R = 1;
+    Taps taps; memset(&taps, 0, sizeof(taps));
+    for (int i = 0; i < nkx; ++i) taps.x[R - nkx / 2 + i] = kx[i];
+    for (int i = 0; i < nky; ++i) taps.y[R - nky / 2 + i] = ky[i];
+    const View s = make_view(src), d = make_view(dst);
+    hipStream_t st = (hipStream_t)stream;
+    switch (src->c) {
+        case 1: return sepconv_tile_c1(R, s, d, df, taps, border, st);
+        case 3: return sepconv_tile_c3(R, s, d, df, taps, border, st);
+        case 4: return sepconv_tile_c4(R, s, d, df, taps, border, st);
+        default: return IMGXF_ERR_UNSUPPORTED;
+    }
+}
+} // namespace imgxf
+
+using namespace imgxf;
+
+IMGXF_API int imgxf_sepconv_u8(const imgxf_view* src, const imgxf_view* dst, const float* kx,
+                               int nkx, const float* ky, int nky, int border,
+                               const imgxf_view* dst_f32, void* stream) {
+    return run_sepconv(src, dst, kx, nkx, ky, nky, border, dst_f32, stream);
+}
+
+IMGXF_API int imgxf_gaussian_u8(const imgxf_view* src, const imgxf_view* dst, int ksize,
+                                double sigma, const imgxf_view* dst_f32, void* stream) {
+    if (ksize < 1 || !(ksize & 1) || ksize > 31) return IMGXF_ERR_ARG;
+    if (sigma <= 0) sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8;
+    double kd[31], sum = 0.0;
+    for (int i = 0; i < ksize; ++i) {
+        const double x = i - (ksize - 1) * 0.5;
+        kd[i] = exp(-(x * x) / (2.0 * sigma * sigma));
+        sum += kd[i];
+    }
+    float kf[31];
+    for (int i = 0; i < ksize; ++i) kf[i] = (float)(kd[i] / sum);
+    return run_sepconv(src, dst, kf, ksize, kf, ksize, IMGXF_BORDER_REFLECT_101, dst_f32, stream);
+}

@@ -1,0 +1,374 @@
+"""Batched device-tensor API over libimgxf (one HIP launch per op, no host round trips).
+
+Every function takes uint8 ROCm tensors shaped [N,H,W,C], [H,W,C] or [H,W] (interleaved,
+exactly the layout `np.array(pil_image)` has at /root/reference/transformation.py:204,229,273)
+and returns a new tensor of the same rank on the same device.  Work is enqueued on the
+current torch stream; nothing synchronises.  These are the batched twins of the
+reference's per-image library calls — the PIL facade in `transformation.py` is a thin
+H2D -> op -> D2H wrapper around them.
+"""
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+
+from . import _ffi as F
+
+NEAREST, BILINEAR, BICUBIC = F.FILTER_NEAREST, F.FILTER_BILINEAR, F.FILTER_BICUBIC
+REFLECT_101, REFLECT = F.BORDER_REFLECT_101, F.BORDER_REFLECT
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check_u8(t: torch.Tensor, name: str = "image") -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
+    if t.dtype != torch.uint8:
+        raise TypeError(f"{name} must be uint8, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on a ROCm device (got {t.device}); libimgxf has no CPU path")
+    if t.dim() not in (2, 3, 4):
+        raise ValueError(f"{name} must be [N,H,W,C], [H,W,C] or [H,W]; got shape {tuple(t.shape)}")
+    if t.dim() >= 3 and t.shape[-1] > 1 and t.stride(-1) != 1 or (t.dim() >= 3 and t.shape[-2] > 1 and t.stride(-2) != t.shape[-1]):
+        t = t.contiguous()
+    if t.dim() == 2 and t.shape[-1] > 1 and t.stride(-1) != 1:
+        t = t.contiguous()
+    return t
+
+
+def _like(t: torch.Tensor, h: int | None = None, w: int | None = None, c: int | None = None,
+          dtype=torch.uint8) -> torch.Tensor:
+    """Fresh contiguous tensor with t's rank and optionally different H/W/C."""
+    shape = list(t.shape)
+    if t.dim() == 2:
+        if h is not None: shape[0] = h
+        if w is not None: shape[1] = w
+        if c is not None and c != 1:
+            shape = shape + [c]
+    else:
+        if h is not None: shape[-3] = h
+        if w is not None: shape[-2] = w
+        if c is not None: shape[-1] = c
+    return torch.empty(shape, dtype=dtype, device=t.device)
+
+
+def _hwc(t: torch.Tensor):
+    if t.dim() == 2:
+        return t.shape[0], t.shape[1], 1
+    return t.shape[-3], t.shape[-2], t.shape[-1]
+
+
+# ---------------------------------------------------------------- a1 Gaussian / separable
+def gaussian_blur(t: torch.Tensor, ksize: int, sigma: float, return_f32: bool = False):
+    """cv2.GaussianBlur(img, (ksize, ksize), sigma) — transformation.py:249."""
+    t = _check_u8(t)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    f32 = torch.empty(t.shape, dtype=torch.float32, device=t.device) if return_f32 else None
+    F.call("imgxf_gaussian_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), int(ksize), float(sigma),
+           F.vp(F.view_of(f32)) if return_f32 else None, _stream())
+    return (out, f32) if return_f32 else out
+
+
+def sepconv(t: torch.Tensor, kx: Sequence[float], ky: Sequence[float], border: int = REFLECT_101,
+            return_f32: bool = False):
+    t = _check_u8(t)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    f32 = torch.empty(t.shape, dtype=torch.float32, device=t.device) if return_f32 else None
+    F.call("imgxf_sepconv_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(kx), len(kx),
+           F.f32_array(ky), len(ky), border, F.vp(F.view_of(f32)) if return_f32 else None, _stream())
+    return (out, f32) if return_f32 else out
+
+
+# ---------------------------------------------------------------- a5 dense correlation
+def conv2d(t: torch.Tensor, kernel, border: int = REFLECT_101) -> torch.Tensor:
+    """cv2.filter2D(img, -1, kernel) — cifar_image_transformations.py:118."""
+    t = _check_u8(t)
+    rows = [list(map(float, r)) for r in kernel]
+    kh, kw = len(rows), len(rows[0])
+    if any(len(r) != kw for r in rows):
+        raise ValueError("kernel must be rectangular")
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    flat = [v for r in rows for v in r]
+    F.call("imgxf_conv2d_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(flat), kh, kw,
+           border, _stream())
+    return out
+
+
+# ---------------------------------------------------------------- a4 Sobel
+def sobel(gray: torch.Tensor, variant: int = F.SOBEL_X_WRAP) -> torch.Tensor:
+    """scipy.ndimage.sobel(gray_u8) — transformation.py:339 (variant 0), or |G| (variant 2)."""
+    gray = _check_u8(gray, "gray")
+    out = torch.empty_like(gray, memory_format=torch.contiguous_format)
+    F.call("imgxf_sobel_u8", F.vp(_gray_view(gray)), F.vp(_gray_view(out)), int(variant), _stream())
+    return out
+
+
+def rgb_sobel_magnitude(rgb: torch.Tensor) -> torch.Tensor:
+    """Fused RGB -> L -> (Gx,Gy) -> |G| -> uint8 (benchmark configs[2])."""
+    rgb = _check_u8(rgb)
+    out = _gray_like(rgb)
+    F.call("imgxf_rgb_sobel_mag_u8", F.vp(F.view_of(rgb)), F.vp(_gray_view(out)), _stream())
+    return out
+
+
+def _gray_view(t: torch.Tensor) -> F.View:
+    """View of a single-channel tensor: [H,W], [H,W,1] or [N,H,W,1]."""
+    if t.dim() >= 3 and t.shape[-1] != 1:
+        raise ValueError(f"expected a single-channel image, got shape {tuple(t.shape)}")
+    return F.view_of(t)
+
+
+def _gray_like(t: torch.Tensor) -> torch.Tensor:
+    """Single-channel output for an interleaved input: [N,H,W,C] -> [N,H,W,1], [H,W,C] -> [H,W]."""
+    shape = tuple(t.shape[:-1]) + (1,) if t.dim() == 4 else tuple(t.shape[:2])
+    return torch.empty(shape, dtype=torch.uint8, device=t.device)
+
+
+# ---------------------------------------------------------------- a2 affine family
+def affine(t: torch.Tensor, matrix: Sequence[float], out_size: tuple[int, int] | None = None,
+           resample: int = NEAREST, fillcolor=None, precise: bool = True, return_f32: bool = False):
+    """Image.transform(out_size, AFFINE, matrix, resample, fillcolor=fillcolor).
+
+    `out_size` is (width, height) like Pillow.  NEAREST with a pure scale/translate
+    matrix follows libImaging's ImagingScaleAffine; everything else its generic path."""
+    t = _check_u8(t)
+    h, w, c = _hwc(t)
+    ow, oh = (w, h) if out_size is None else (int(out_size[0]), int(out_size[1]))
+    m = [float(v) for v in matrix][:6]
+    if len(m) != 6:
+        raise ValueError("affine matrix needs 6 coefficients")
+    out = _like(t, oh, ow)
+    fill = _fill_bytes(fillcolor, c)
+    if resample == NEAREST and m[1] == 0.0 and m[3] == 0.0:
+        ws = torch.empty(ow + oh + 2, dtype=torch.int32, device=t.device)
+        F.call("imgxf_affine_scale_nearest_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f64_array(m),
+               fill, ws.data_ptr(), ws.numel() * 4, _stream())
+        return out
+    f32 = None
+    if return_f32:
+        f32 = torch.empty(out.shape, dtype=torch.float32, device=t.device)
+    F.call("imgxf_affine_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f64_array(m), int(resample),
+           fill, 1 if precise else 0, F.vp(F.view_of(f32)) if return_f32 else None, _stream())
+    return (out, f32) if return_f32 else out
+
+
+def _fill_bytes(fillcolor, c: int):
+    if fillcolor is None:
+        return F.u8_array([0] * 4)
+    if isinstance(fillcolor, (int, float)):
+        return F.u8_array([int(fillcolor)] * c)
+    return F.u8_array(list(fillcolor)[:c])
+
+
+def rotate_matrix(w: int, h: int, angle: float) -> list[float]:
+    """Destination->source matrix built by Image.rotate (PIL/Image.py:2538-2568),
+    expand=False, default centre, no translate."""
+    cx, cy = w / 2, h / 2
+    a = -math.radians(angle % 360.0)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0,
+         round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    m[2] = m[0] * -cx + m[1] * -cy + m[2]
+    m[5] = m[3] * -cx + m[4] * -cy + m[5]
+    m[2] += cx
+    m[5] += cy
+    return m
+
+
+def rotate_zoom_matrix(w: int, h: int, angle_deg: float, zoom: float) -> list[float]:
+    """Inverse matrix for 'rotate about the centre by angle_deg and zoom' (benchmark configs[3])."""
+    a = math.radians(angle_deg)
+    c, s = math.cos(a) / zoom, math.sin(a) / zoom
+    cx, cy = w / 2.0, h / 2.0
+    return [c, -s, cx - (c * cx - s * cy), s, c, cy - (s * cx + c * cy)]
+
+
+def rot90(t: torch.Tensor, quarter_turns_ccw: int) -> torch.Tensor:
+    t = _check_u8(t)
+    h, w, _ = _hwc(t)
+    k = quarter_turns_ccw % 4
+    if k == 0:
+        return t.clone()
+    out = _like(t, w, h) if k != 2 else torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_rot90_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), k, _stream())
+    return out
+
+
+def rotate(t: torch.Tensor, angle: float, resample: int = NEAREST, fillcolor=None,
+           precise: bool = True) -> torch.Tensor:
+    """Image.rotate(angle, resample, expand=False, fillcolor=fillcolor) incl. its fast paths."""
+    t = _check_u8(t)
+    h, w, _ = _hwc(t)
+    a = angle % 360.0
+    if a == 0:
+        return t.clone()
+    if a == 180:
+        return rot90(t, 2)
+    if a in (90, 270) and w == h:
+        return rot90(t, 1 if a == 90 else 3)
+    return affine(t, rotate_matrix(w, h, angle), (w, h), resample, fillcolor, precise)
+
+
+# ---------------------------------------------------------------- a3 Lanczos resize
+class _PlanCache:
+    def __init__(self):
+        self._plans: dict = {}
+
+    def get(self, in_h, in_w, out_h, out_w, c, n, device_index):
+        key = (in_h, in_w, out_h, out_w, c, device_index)
+        ent = self._plans.get(key)
+        if ent is not None and ent[1] >= n:
+            return ent[0]
+        if ent is not None:
+            F.call("imgxf_lanczos_plan_destroy", ent[0])
+        import ctypes
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device_index):
+            F.call("imgxf_lanczos_plan_create", ctypes.byref(handle), in_h, in_w, out_h, out_w, c, n)
+        self._plans[key] = (handle, n)
+        return handle
+
+    def clear(self):
+        for handle, _ in self._plans.values():
+            F.lib.imgxf_lanczos_plan_destroy(handle)
+        self._plans.clear()
+
+
+_plans = _PlanCache()
+
+
+def resize_lanczos(t: torch.Tensor, size: tuple[int, int]) -> torch.Tensor:
+    """img.resize((nw, nh), Image.Resampling.LANCZOS) — transformation.py:179."""
+    t = _check_u8(t)
+    h, w, c = _hwc(t)
+    nw, nh = int(size[0]), int(size[1])
+    if nw < 1 or nh < 1:
+        raise ValueError("height and width must be > 0")   # Pillow's message
+    n = t.shape[0] if t.dim() == 4 else 1
+    out = _like(t, nh, nw)
+    if n == 0:
+        return out
+    plan = _plans.get(h, w, nh, nw, c, n, t.device.index or 0)
+    F.call("imgxf_resize_lanczos_u8", plan, F.vp(F.view_of(t)), F.vp(F.view_of(out)), _stream())
+    return out
+
+
+# ---------------------------------------------------------------- crop / paste / fill
+def new(like: torch.Tensor, h: int, w: int, color=(0, 0, 0)) -> torch.Tensor:
+    """Image.new(mode, (w,h), color) for a batch shaped like `like`."""
+    _, _, c = _hwc(like)
+    out = _like(like, h, w)
+    F.call("imgxf_fill_u8", F.vp(F.view_of(out)), _fill_bytes(color, c), _stream())
+    return out
+
+
+def copy_rect(src: torch.Tensor, dst: torch.Tensor, sx: int, sy: int, dx: int, dy: int, rw: int, rh: int) -> None:
+    src = _check_u8(src, "src")
+    F.call("imgxf_copy_rect_u8", F.vp(F.view_of(src)), F.vp(F.view_of(dst)), sx, sy, dx, dy, rw, rh, _stream())
+
+
+def crop(t: torch.Tensor, box: tuple[int, int, int, int]) -> torch.Tensor:
+    """Image.crop((left, top, right, bottom)) for boxes inside the image."""
+    l, tp, r, b = box
+    out = _like(t, b - tp, r - l)
+    copy_rect(t, out, l, tp, 0, 0, r - l, b - tp)
+    return out
+
+
+# ---------------------------------------------------------------- a6 colour maps
+def rgb2l(t: torch.Tensor) -> torch.Tensor:
+    """img.convert('L') — transformation.py:336."""
+    t = _check_u8(t)
+    if t.dim() < 3:
+        raise ValueError("rgb2l expects an interleaved RGB(A) image")
+    out = _gray_like(t)
+    F.call("imgxf_rgb2l_u8", F.vp(F.view_of(t)), F.vp(_gray_view(out)), _stream())
+    return out
+
+
+def scale_abs(t: torch.Tensor, alpha: float, beta: float = 0.0) -> torch.Tensor:
+    """cv2.convertScaleAbs(img, alpha=alpha, beta=beta) — transformation.py:207."""
+    t = _check_u8(t)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_scale_abs_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(alpha), float(beta), _stream())
+    return out
+
+
+def blend(im1, im2, alpha: float, like: torch.Tensor | None = None) -> torch.Tensor:
+    """Image.blend(im1, im2, alpha); either image may be a solid colour tuple."""
+    t1 = im1 if isinstance(im1, torch.Tensor) else None
+    t2 = im2 if isinstance(im2, torch.Tensor) else None
+    ref = t1 if t1 is not None else (t2 if t2 is not None else like)
+    if ref is None:
+        raise ValueError("blend needs at least one image tensor")
+    ref = _check_u8(ref)
+    _, _, c = _hwc(ref)
+    if t1 is not None: t1 = _check_u8(t1, "im1")
+    if t2 is not None: t2 = _check_u8(t2, "im2")
+    if t1 is not None and t2 is not None and t1.shape != t2.shape:
+        raise ValueError("images do not match")   # Pillow's message
+    out = torch.empty_like(ref, memory_format=torch.contiguous_format)
+    F.call("imgxf_blend_u8",
+           F.vp(F.view_of(t1)) if t1 is not None else None, None if t1 is not None else _fill_bytes(im1, c),
+           F.vp(F.view_of(t2)) if t2 is not None else None, None if t2 is not None else _fill_bytes(im2, c),
+           F.vp(F.view_of(out)), float(alpha), _stream())
+    return out
+
+
+def brightness(t: torch.Tensor, factor: float) -> torch.Tensor:
+    """ImageEnhance.Brightness(img).enhance(factor) = Image.blend(black, img, factor)."""
+    return blend((0, 0, 0, 0), t, factor)
+
+
+def add_noise(t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """np.clip(img.astype(f32) + noise, 0, 255).astype(u8) — transformation.py:275-278."""
+    t = _check_u8(t)
+    if noise.dtype != torch.float32 or noise.shape != t.shape or not noise.is_cuda:
+        raise ValueError("noise must be a float32 device tensor shaped like the image")
+    noise = noise.contiguous()
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_add_noise_u8", F.vp(F.view_of(t)), F.vp(F.view_of(noise)), F.vp(F.view_of(out)), _stream())
+    return out
+
+
+def permute_channels(t: torch.Tensor, perm: Sequence[int]) -> torch.Tensor:
+    """cv2.cvtColor channel shuffles: out[..., j] = t[..., perm[j]]."""
+    t = _check_u8(t)
+    out = _like(t, c=len(perm))
+    F.call("imgxf_permute_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.i32_array(perm), _stream())
+    return out
+
+
+def composite(im1: torch.Tensor, im2: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """Image.composite(im1, im2, mask) for a 0/255 single-channel mask."""
+    im1, im2, mask = _check_u8(im1), _check_u8(im2), _check_u8(mask, "mask")
+    out = torch.empty_like(im1, memory_format=torch.contiguous_format)
+    F.call("imgxf_composite_u8", F.vp(F.view_of(im1)), F.vp(F.view_of(im2)), F.vp(_gray_view(mask)),
+           F.vp(F.view_of(out)), _stream())
+    return out
+
+
+# ---------------------------------------------------------------- mask stage
+def percentile_mask(gray: torch.Tensor, q: float, return_threshold: bool = False):
+    """(gray > np.percentile(gray, q)) * 255 per frame — transformation.py:340."""
+    gray = _check_u8(gray, "gray")
+    n = gray.shape[0] if gray.dim() == 4 else 1
+    hist = torch.empty((n, 256), dtype=torch.int32, device=gray.device)
+    thr = torch.empty(n, dtype=torch.float64, device=gray.device)
+    out = torch.empty_like(gray, memory_format=torch.contiguous_format)
+    gv = _gray_view(gray)
+    F.call("imgxf_histogram_u8", F.vp(gv), hist.data_ptr(), _stream())
+    F.call("imgxf_percentile_mask_u8", F.vp(gv), hist.data_ptr(), float(q), F.vp(_gray_view(out)),
+           thr.data_ptr(), _stream())
+    return (out, thr) if return_threshold else out
+
+
+def dilate_cross(mask: torch.Tensor, iterations: int) -> torch.Tensor:
+    """scipy.ndimage.binary_dilation(mask, iterations=iterations) on 0/255 masks."""
+    mask = _check_u8(mask, "mask")
+    out = torch.empty_like(mask, memory_format=torch.contiguous_format)
+    F.call("imgxf_dilate_cross_u8", F.vp(_gray_view(mask)), F.vp(_gray_view(out)), int(iterations), _stream())
+    return out

@@ -1,0 +1,250 @@
+"""Drop-in for the reference's `transformation.py` per-image functions, backed by HIP.
+
+Same names, argument meaning, return types and error behaviour as
+/root/reference/transformation.py:173-354 (`apply_<x>(img: PIL.Image, ...) -> PIL.Image`)
+and its driver `apply_all_transformations` (:92-170).  Each body is
+    PIL image -> uint8 HWC device tensor -> libimgxf kernel(s) -> PIL image
+and fails loudly when the HIP library or a ROCm device is missing (no CPU path).
+Batches of frames should use `imagetransformations_amd.ops` directly and stay on the device.
+"""
+from __future__ import annotations
+
+import math
+import os
+import random
+from typing import List, Tuple
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import ops
+
+# Where apply_all_transformations writes its JPEGs (the reference hard-codes a
+# /Users/... path at transformation.py:13-17).  None = do not write files.
+output_dir: str | None = os.environ.get("IMGXF_OUTPUT_DIR")
+
+TRANSFORMATIONS_2D = {                      # transformation.py:95-105
+    'scale': {'min': 0.9, 'max': 1.4, 'step': 0.1},
+    'rotation': {'min': -22.5, 'max': 22.5, 'step': 2.5},
+    'lighten_darken': {'min': -0.05, 'max': 0.05, 'step': 0.01},
+    'gaussian_noise': {'min': 0.0, 'max': 0.1, 'step': 0.01},
+    'translation': {'min': -50, 'max': 50, 'step': 5},
+    'contrast': {'min': 0, 'max': 1, 'step': 0.1},
+    'blur': {'min': 0, 'max': 5, 'step': 0.5},
+    'shear': {'min': 0, 'max': 1, 'step': 0.1},
+}
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("imagetransformations_amd needs a ROCm device (MI355X); none is visible "
+                           "and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _upload(img: Image.Image) -> torch.Tensor:
+    """np.array(img) (HWC / HW uint8) -> device tensor."""
+    arr = np.array(img)
+    if arr.dtype != np.uint8:
+        raise TypeError(f"only 8-bit images are supported, got mode {img.mode!r}")
+    return torch.from_numpy(arr).to(_device(), non_blocking=False)
+
+
+def _download(t: torch.Tensor) -> Image.Image:
+    """Image.fromarray(device tensor) (synchronises on the copy)."""
+    return Image.fromarray(t.cpu().numpy())
+
+
+def _drop_alpha(t: torch.Tensor) -> torch.Tensor:
+    return ops.permute_channels(t, (0, 1, 2)) if t.dim() == 3 and t.shape[2] == 4 else t
+
+
+# ------------------------------------------------------------------ scale (:173-196)
+def apply_scale(img: Image.Image, scale_factor: float) -> Image.Image:
+    width, height = img.size
+    new_width = int(width * scale_factor)
+    new_height = int(height * scale_factor)
+    t = _upload(img)
+    scaled = ops.resize_lanczos(t, (new_width, new_height))
+    if scale_factor > 1.0:
+        left = (new_width - width) // 2
+        top = (new_height - height) // 2
+        scaled = ops.crop(scaled, (left, top, left + width, top + height))
+    elif scale_factor < 1.0:
+        canvas = ops.new(scaled, height, width, (0, 0, 0))
+        ops.copy_rect(scaled, canvas, 0, 0, (width - new_width) // 2, (height - new_height) // 2,
+                      new_width, new_height)
+        scaled = canvas
+    return _download(scaled)
+
+
+# ------------------------------------------------------------------ rotation (:198-201)
+def apply_rotation(img: Image.Image, angle: float) -> Image.Image:
+    return _download(ops.rotate(_upload(img), -angle, ops.NEAREST, fillcolor=(0, 0, 0)))
+
+
+# ------------------------------------------------------------------ contrast (:203-210)
+def apply_contrast(img: Image.Image, contrast_amount: float) -> Image.Image:
+    t = _upload(img)
+    if t.dim() == 2:
+        raise IndexError("tuple index out of range")   # img_np.shape[2] on a 2-D array (:205)
+    return _download(ops.scale_abs(_drop_alpha(t), contrast_amount, 0.0))
+
+
+# ------------------------------------------------------------------ shear (:212-226)
+def apply_shear(img: Image.Image, shear_factor: float) -> Image.Image:
+    width, height = img.size
+    shift_in_pixels = int(math.ceil(shear_factor * height))
+    matrix = (1, shear_factor, -shift_in_pixels if shear_factor > 0 else 0, 0, 1, 0)
+    out = ops.affine(_upload(img), matrix, (width + shift_in_pixels, height), ops.BICUBIC,
+                     fillcolor=(255, 255, 255))
+    return _download(out)
+
+
+# ------------------------------------------------------------------ blur (:228-257)
+def apply_blur(img: Image.Image, blur_radius: float) -> Image.Image:
+    ksize = int(blur_radius * 6)
+    if ksize % 2 == 0:
+        ksize += 1
+    if ksize < 3 and blur_radius > 0:
+        ksize = 3
+    elif blur_radius == 0:
+        return img          # the reference hands back the input object itself (:245-246)
+    t = _drop_alpha(_upload(img))
+    return _download(ops.gaussian_blur(t, ksize, blur_radius))
+
+
+# ------------------------------------------------------------------ brightness (:261-269)
+def apply_brightness(img: Image.Image, brightness_factor: float) -> Image.Image:
+    if img.mode not in ("RGB", "L"):
+        raise NotImplementedError(f"apply_brightness supports RGB and L images, got {img.mode!r}")
+    return _download(ops.brightness(_upload(img), 1.0 + brightness_factor))
+
+
+# ------------------------------------------------------------------ gaussian noise (:272-281)
+def apply_gaussian_noise(img: Image.Image, noise_std: float) -> Image.Image:
+    """The noise is drawn on the host from NumPy's global generator exactly as the reference
+    does (same stream for the same np.random.seed), then added and clipped on the device."""
+    img_array = np.array(img)
+    noise = np.random.normal(0, noise_std * 255, img_array.shape).astype(np.float32)
+    dev = _device()
+    out = ops.add_noise(torch.from_numpy(img_array).to(dev), torch.from_numpy(noise).to(dev))
+    return _download(out)
+
+
+# ------------------------------------------------------------------ translation (:284-307)
+def apply_translation(img: Image.Image, tx: float, ty: float) -> Image.Image:
+    width, height = img.size
+    t = _upload(img.convert('RGB') if img.mode != 'RGB' else img)
+    result = ops.new(t, height, width, (0, 0, 0))
+    paste_x, paste_y = int(tx), int(ty)
+    crop_left, crop_top = max(0, -paste_x), max(0, -paste_y)
+    crop_right, crop_bottom = min(width, width - paste_x), min(height, height - paste_y)
+    if crop_left < crop_right and crop_top < crop_bottom:
+        ops.copy_rect(t, result, crop_left, crop_top, max(0, paste_x), max(0, paste_y),
+                      crop_right - crop_left, crop_bottom - crop_top)
+    return _download(result)
+
+
+def apply_camera_distance(img: Image.Image, distance_factor: float) -> Image.Image:   # :309-314
+    return apply_scale(img, 2.75 / distance_factor)
+
+
+def apply_xy_translation_3d(img: Image.Image, tx: float, ty: float) -> Image.Image:   # :316-321
+    width, height = img.size
+    return apply_translation(img, int(tx * width), int(ty * height))
+
+
+def apply_rotation_3d(img: Image.Image, angle: float) -> Image.Image:                 # :324-325
+    return apply_rotation(img, angle)
+
+
+# ------------------------------------------------------------------ background (:328-354)
+def _rgb_tensor(img: Image.Image) -> torch.Tensor:
+    t = _upload(img)
+    if t.dim() == 2:
+        raise NotImplementedError("background change expects a colour image")
+    return _drop_alpha(t)
+
+
+def apply_background_change(img: Image.Image, bg_color: Tuple[float, float, float]) -> Image.Image:
+    bg_rgb = tuple(int(c * 255) for c in bg_color)
+    rgb = _rgb_tensor(img)
+    background = ops.new(rgb, rgb.shape[0], rgb.shape[1], bg_rgb)
+    edges = ops.sobel(ops.rgb2l(rgb))                     # ndimage.sobel(gray) (:339)
+    edge_mask = ops.percentile_mask(edges, 70)            # edges > np.percentile(edges, 70)
+    foreground = ops.dilate_cross(edge_mask, 3)           # binary_dilation(iterations=3)
+    return _download(ops.composite(rgb, background, foreground))
+
+
+def apply_background_change_simple(img: Image.Image, bg_color: Tuple[float, float, float]) -> Image.Image:
+    bg_rgb = tuple(int(c * 255) for c in bg_color)
+    return _download(ops.blend(_rgb_tensor(img), bg_rgb, 0.3))
+
+
+# ------------------------------------------------------------------ driver (:73-170)
+def load_data(data_path):
+    """Walk `data_path`, open every *.jpeg as RGB -> [(PIL image, path)] (:73-89)."""
+    image_paths = []
+    for root, _, files in os.walk(data_path):
+        image_paths.extend(os.path.join(root, f) for f in files if f.lower().endswith('.jpeg'))
+    images = []
+    for path in image_paths:
+        try:
+            images.append((Image.open(path).convert("RGB"), path))
+        except Exception as e:      # the reference only guards the file loading
+            print(f"Failed to load image {path}: {e}")
+    print(f"Loaded {len(images)} images.")
+    return images
+
+
+_DISPATCH = {
+    'scale': apply_scale,
+    'rotation': apply_rotation,
+    'lighten_darken': apply_brightness,
+    'gaussian_noise': apply_gaussian_noise,
+    'contrast': apply_contrast,
+    'shear': apply_shear,
+    'blur': apply_blur,
+}
+
+
+def grid_values(params) -> List[float]:
+    """min + j*step for j < int((max-min)/step)+1 — float artefacts included (:126-127)."""
+    num_steps = int((params['max'] - params['min']) / params['step']) + 1
+    return [params['min'] + j * params['step'] for j in range(num_steps)]
+
+
+def plan_transformations(name: str):
+    """One random draw per transform type in the reference's order -> [(type, args, filename)].
+    Consumes `random` exactly like the loop at transformation.py:119-139."""
+    plan = []
+    for transform_type, params in TRANSFORMATIONS_2D.items():
+        values = grid_values(params)
+        if transform_type == 'translation':
+            tx = random.choice(values)
+            ty = random.choice(values)
+            plan.append((transform_type, (tx, ty), f"{name}_{transform_type}_{tx}_{ty}_corrupted.jpg"))
+        else:
+            value = random.choice(values)
+            plan.append((transform_type, (value,), f"{name}_{transform_type}_{value}_corrupted.jpg"))
+    return plan
+
+
+def apply_all_transformations(images):
+    """images: [(PIL image, path)] -> list of transformed PIL images (8 per input)."""
+    transformed_images = []
+    total_transforms = 0
+    for i, (img, path) in enumerate(images):
+        name = os.path.splitext(os.path.basename(path))[0]
+        for transform_type, args, new_filename in plan_transformations(name):
+            fn = apply_translation if transform_type == 'translation' else _DISPATCH[transform_type]
+            transformed_img = fn(img, *args)
+            if output_dir is not None:
+                transformed_img.save(os.path.join(output_dir, new_filename))
+            transformed_images.append(transformed_img)
+            total_transforms += 1
+        if (i + 1) % 1000 == 0:
+            print(f"Processed {i + 1}/{len(images)} original images, created {total_transforms} transformed images")
+    return transformed_images

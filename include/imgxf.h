@@ -1,0 +1,178 @@
+/*
+ * imgxf.h — C-ABI of libimgxf.so: MI355X (gfx950) HIP kernels for the per-pixel
+ * transform hot path of aaryaamoharir/ImageTransformations.
+ *
+ * The reference has no FFI of its own: its boundary is a set of Python functions
+ * (`apply_<x>(img: PIL.Image, params) -> PIL.Image`, /root/reference/transformation.py:173-354,
+ * and `TransformationPool.<x>`, /root/reference/pipenline/cifar_image_transformations.py:37-129)
+ * whose bodies call Pillow / OpenCV / SciPy / NumPy C kernels.  Each entry point below
+ * replaces ONE of those third-party calls; the call site it replaces is cited.  The
+ * Python facade (imagetransformations_amd/transformation.py) binds these with ctypes
+ * exactly as INTEGRATION.md shows.
+ *
+ * Conventions
+ *   - every function returns IMGXF_OK (0), a negative imgxf error, or a positive hipError_t;
+ *     nothing throws; nothing allocates or synchronises unless its comment says so;
+ *   - all pixel pointers are DEVICE pointers (e.g. torch tensor .data_ptr()); the caller owns
+ *     every buffer; `stream` is a hipStream_t (NULL = the default stream); calls are ordered
+ *     by the stream only and are re-entrant;
+ *   - images are interleaved (HWC) batches described by imgxf_view; strides are in BYTES;
+ *     src and dst must not overlap unless the comment says in-place is allowed;
+ *   - small host-side parameter arrays (kernels, matrices, colours) are HOST pointers that
+ *     are copied into the kernel arguments before the call returns.
+ */
+#ifndef IMGXF_H
+#define IMGXF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMGXF_VERSION 100 /* 0.1.0 */
+
+enum {
+    IMGXF_OK = 0,
+    IMGXF_ERR_NULL = -1,        /* a required pointer is NULL */
+    IMGXF_ERR_SHAPE = -2,       /* n/h/w/c or strides inconsistent between views */
+    IMGXF_ERR_ARG = -3,         /* scalar argument out of range */
+    IMGXF_ERR_UNSUPPORTED = -4, /* valid request this build has no kernel for */
+    IMGXF_ERR_WORKSPACE = -5,   /* workspace too small */
+    IMGXF_ERR_NO_DEVICE = -6    /* no gfx950-compatible device / code object */
+};
+
+/* A batch of n interleaved frames: pixel (f,y,x,ch) lives at
+ * data + f*frame_stride + y*row_stride + (x*c + ch)*elem_size. */
+typedef struct imgxf_view {
+    void*   data;
+    int32_t n, h, w, c;
+    int64_t row_stride;
+    int64_t frame_stride;
+} imgxf_view;
+
+enum { IMGXF_BORDER_REFLECT_101 = 0, /* gfedcb|abcdefgh|gfedcba (OpenCV default) */
+       IMGXF_BORDER_REFLECT = 1      /* dcba|abcd|dcba (SciPy ndimage 'reflect') */ };
+
+enum { IMGXF_FILTER_NEAREST = 0, IMGXF_FILTER_BILINEAR = 1, IMGXF_FILTER_BICUBIC = 2 };
+
+enum { IMGXF_SOBEL_X_WRAP = 0,    /* scipy.ndimage.sobel(u8, axis=-1): result mod 256 */
+       IMGXF_SOBEL_Y_WRAP = 1,    /* axis=0 */
+       IMGXF_SOBEL_MAGNITUDE = 2  /* sat_u8(rint(sqrt(Gx^2+Gy^2))) — benchmark configs[2] */ };
+
+int         imgxf_version(void);
+const char* imgxf_strerror(int code);
+/* Number of visible HIP devices whose architecture this library was built for (>=0),
+ * or a negative error.  Does not create a context on any device. */
+int         imgxf_device_count(void);
+
+/* ---- a1: cv2.GaussianBlur(img,(k,k),sigma)  transformation.py:249 -------------------
+ * Separable Gaussian, BORDER_REFLECT_101, fp32 accumulate, round-half-even, saturate.
+ * c in {1,3,4}; ksize odd, 1..31.  sigma<=0 uses OpenCV's 0.3*((k-1)*0.5-1)+0.8.
+ * `dst_f32` (optional, may be NULL): if given, a float view of the same n,h,w,c that
+ * receives the pre-quantisation fp32 values (diagnostic; used by the parity tests). */
+int imgxf_gaussian_u8(const imgxf_view* src, const imgxf_view* dst, int ksize, double sigma,
+                      const imgxf_view* dst_f32, void* stream);
+
+/* Generic separable correlation with host-given fp32 taps (kx along x, ky along y). */
+int imgxf_sepconv_u8(const imgxf_view* src, const imgxf_view* dst, const float* kx, int nkx,
+                     const float* ky, int nky, int border, const imgxf_view* dst_f32,
+                     void* stream);
+
+/* ---- a5: cv2.filter2D(img,-1,kernel)  cifar_image_transformations.py:118 ------------
+ * Dense kh x kw correlation, centre anchor, fp32 accumulate, round-half-even, saturate.
+ * kernel: HOST pointer, row-major kh*kw floats; kh,kw odd, <= 15. */
+int imgxf_conv2d_u8(const imgxf_view* src, const imgxf_view* dst, const float* kernel, int kh,
+                    int kw, int border, void* stream);
+
+/* ---- a4: scipy.ndimage.sobel(gray_u8)  transformation.py:339 ------------------------
+ * src, dst: c == 1.  variant: IMGXF_SOBEL_*.  Border: SciPy 'reflect'. */
+int imgxf_sobel_u8(const imgxf_view* src, const imgxf_view* dst, int variant, void* stream);
+/* Fused benchmark configs[2]: RGB(c==3) -> L (Pillow weights) -> Gx,Gy -> magnitude -> u8 (c==1). */
+int imgxf_rgb_sobel_mag_u8(const imgxf_view* src, const imgxf_view* dst, void* stream);
+
+/* ---- a2/a2'/shear: Image.transform(size, AFFINE, m, resample, fillcolor) -------------
+ * transformation.py:200 (rotate -> NEAREST), :217-224 (shear -> BICUBIC); BILINEAR is
+ * benchmark configs[3].  m[6]: HOST pointer, destination->source matrix exactly as Pillow
+ * takes it.  dst gives the output size.  fill[4]: HOST pointer (per channel), NULL = zeros.
+ * NEAREST reproduces libImaging affine_fixed (16.16) bit-exactly when m[1]!=0 or m[3]!=0;
+ * pure scale/translate NEAREST matrices need imgxf_affine_scale_nearest_u8.
+ * precise != 0: coordinates and interpolation in fp64 (bit-exact with Pillow);
+ * precise == 0: fp64 coordinates, fp32 interpolation (<=1e-5 relative before truncation).
+ * `dst_f32` (optional, may be NULL; BILINEAR/BICUBIC only): float view of dst's n,h,w,c that
+ * receives the pre-truncation interpolated values (diagnostic; used by the parity tests). */
+int imgxf_affine_u8(const imgxf_view* src, const imgxf_view* dst, const double* m, int filter,
+                    const uint8_t* fill, int precise, const imgxf_view* dst_f32, void* stream);
+/* libImaging ImagingScaleAffine (NEAREST with m[1]==m[3]==0): source indices are walked on
+ * one device lane per axis by the same repeated double additions Pillow performs, into
+ * `workspace` (device, 4-byte aligned, >= 4*(dst->w + dst->h + 2) bytes). */
+int imgxf_affine_scale_nearest_u8(const imgxf_view* src, const imgxf_view* dst, const double* m,
+                                  const uint8_t* fill, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+
+/* ---- a3: img.resize((nw,nh), LANCZOS)  transformation.py:179 -------------------------
+ * Two-pass integer resample (22-bit coefficients computed on the host in double exactly as
+ * libImaging precompute_coeffs/normalize_coeffs_8bpc).  A plan owns the device coefficient
+ * tables and the uint8 intermediate for up to `max_frames` frames; create/destroy allocate,
+ * synchronise and must not be called inside stream capture; the resize call only launches.
+ * A plan may be in use on one stream at a time (its intermediate is shared). */
+typedef struct imgxf_lanczos_plan imgxf_lanczos_plan;
+int imgxf_lanczos_plan_create(imgxf_lanczos_plan** plan, int in_h, int in_w, int out_h,
+                              int out_w, int c, int max_frames);
+int imgxf_lanczos_plan_destroy(imgxf_lanczos_plan* plan);
+int imgxf_resize_lanczos_u8(const imgxf_lanczos_plan* plan, const imgxf_view* src,
+                            const imgxf_view* dst, void* stream);
+
+/* ---- a6: elementwise colour maps ------------------------------------------------------*/
+/* Pillow convert('L') transformation.py:336: (19595R+38470G+7471B+0x8000)>>16. src c in {3,4}, dst c==1 */
+int imgxf_rgb2l_u8(const imgxf_view* src, const imgxf_view* dst, void* stream);
+/* cv2.convertScaleAbs(img, alpha, beta) transformation.py:207: sat_u8(rint(|alpha*p+beta|)). In-place ok. */
+int imgxf_scale_abs_u8(const imgxf_view* src, const imgxf_view* dst, float alpha, float beta,
+                       void* stream);
+/* Image.blend(im1, im2, alpha) (libImaging Blend.c) transformation.py:267,354:
+ * f32 `p1 + alpha*(p2-p1)`; 0<=alpha<=1 truncates, else clip then truncate.
+ * im2 == NULL: the second image is the solid colour `color2[c]` (HOST pointer).
+ * im1 == NULL: the first image is the solid colour `color1[c]`.  In-place ok. */
+int imgxf_blend_u8(const imgxf_view* im1, const uint8_t* color1, const imgxf_view* im2,
+                   const uint8_t* color2, const imgxf_view* dst, float alpha, void* stream);
+/* transformation.py:275-278: clip(f32(p)+noise,0,255) truncated; noise: float view, same n,h,w,c. */
+int imgxf_add_noise_u8(const imgxf_view* src, const imgxf_view* noise_f32, const imgxf_view* dst,
+                       void* stream);
+/* cv2.cvtColor channel permutations (RGB2BGR, RGBA2RGB, ...) transformation.py:206,233-235,252:
+ * dst[..., j] = src[..., perm[j]] for j < dst->c.  perm: HOST pointer. */
+int imgxf_permute_u8(const imgxf_view* src, const imgxf_view* dst, const int32_t* perm,
+                     void* stream);
+/* Image.composite(im1, im2, mask) transformation.py:344 for a 0/255 mask (c==1): mask ? im1 : im2. */
+int imgxf_composite_u8(const imgxf_view* im1, const imgxf_view* im2, const imgxf_view* mask,
+                       const imgxf_view* dst, void* stream);
+
+/* ---- crop / paste / fill (Image.crop, Image.paste, Image.new) transformation.py:187-193,287-305 */
+/* Fill every pixel of dst with color[c] (HOST pointer). */
+int imgxf_fill_u8(const imgxf_view* dst, const uint8_t* color, void* stream);
+/* Copy the rectangle (sx,sy,rw,rh) of src to (dx,dy) of dst for every frame (same n, c). */
+int imgxf_copy_rect_u8(const imgxf_view* src, const imgxf_view* dst, int sx, int sy, int dx,
+                       int dy, int rw, int rh, void* stream);
+/* Image.transpose(ROTATE_90/180/270) fast paths of Image.rotate (PIL/Image.py:2513-2521).
+ * quarter_turns_ccw in {1,2,3}. */
+int imgxf_rot90_u8(const imgxf_view* src, const imgxf_view* dst, int quarter_turns_ccw,
+                   void* stream);
+
+/* ---- mask stage of apply_background_change  transformation.py:340-341 -----------------*/
+/* 256-bin histogram per frame of a c==1 view into hist[n][256] (uint32, device, zeroed by the call). */
+int imgxf_histogram_u8(const imgxf_view* src, uint32_t* hist, void* stream);
+/* mask = (src > np.percentile(src, q)) ? 255 : 0 per frame, threshold derived on the device
+ * from `hist` (numpy 'linear' method).  thr_out: device double[n] (required), receives the
+ * percentile of every frame. */
+int imgxf_percentile_mask_u8(const imgxf_view* src, const uint32_t* hist, double q,
+                             const imgxf_view* dst, double* thr_out, void* stream);
+/* scipy.ndimage.binary_dilation(mask, iterations) with the 4-connected cross, border 0:
+ * equals "L1 distance <= iterations" for this structuring element.  0/255 masks, c==1.
+ * iterations in 1..16. */
+int imgxf_dilate_cross_u8(const imgxf_view* src, const imgxf_view* dst, int iterations,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMGXF_H */

@@ -1,0 +1,753 @@
+"""CPU oracle for the per-pixel transform hot path (TEST INFRASTRUCTURE ONLY).
+
+This module is a NumPy restatement of the arithmetic that the reference
+(`/root/reference/transformation.py`, `/root/reference/pipenline/cifar_image_transformations.py`)
+delegates to Pillow / SciPy / NumPy / OpenCV.  It is the *checker* for the HIP
+kernels: only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` may import it.  The product package `imagetransformations_amd` never
+imports anything from `oracle/`.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * Pillow- / SciPy- / NumPy-backed functions (rotate-nearest, affine bilinear /
+    bicubic, Lanczos resize, blend / brightness, convert('L'), ndimage.sobel,
+    percentile, binary_dilation, composite, translation, shear): PINNED.  They are
+    checked bit-for-bit against the installed Pillow 12.2.0 / SciPy 1.15.3 called
+    with the reference's own argument lists (tests/test_oracle_vs_libs.py) and
+    against the committed fixtures in tests/golden/ (made by tests/golden/make_golden.py).
+  * OpenCV-backed functions (cv2.GaussianBlur `transformation.py:249`,
+    cv2.convertScaleAbs `transformation.py:207`, cv2.filter2D
+    `cifar_image_transformations.py:118`): PARITY UNPINNED.  OpenCV (unpinned version in
+    the reference's requirements) is not installed here and there is no network; the
+    restatement follows OpenCV's documented definitions (Gaussian kernel formula,
+    BORDER_REFLECT_101, saturate_cast round-half-even, convertScaleAbs = sat(|a*p+b|)).
+    Real cv2 uses 8-bit fixed-point kernels for uint8 images, so +-1 LSB residuals
+    against a real cv2 build are expected; the contract (BASELINE.json north_star) is
+    the float definition to 1e-5 relative.
+
+All image arrays are HWC (or HW) uint8, C-contiguous, RGB order — exactly what
+`np.array(pil_image)` yields at `transformation.py:204,229,273`.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+__all__ = [name for name in dir() if not name.startswith("_")]
+
+# ----------------------------------------------------------------------------
+# borders
+# ----------------------------------------------------------------------------
+
+def reflect101_index(i, n):
+    """BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba); == numpy pad mode 'reflect'.
+
+    OpenCV default border for GaussianBlur / filter2D (transformation.py:249,
+    cifar_image_transformations.py:118)."""
+    i = np.asarray(i)
+    if n == 1:
+        return np.zeros_like(i)
+    p = 2 * (n - 1)
+    i = np.mod(i, p)
+    return np.where(i >= n, p - i, i)
+
+
+def reflect_index(i, n):
+    """SciPy ndimage mode='reflect' (dcba|abcd|dcba); == numpy pad mode 'symmetric'.
+
+    Default mode of scipy.ndimage.sobel (transformation.py:339)."""
+    i = np.asarray(i)
+    p = 2 * n
+    i = np.mod(i, p)
+    return np.where(i >= n, p - 1 - i, i)
+
+
+def _as3d(img):
+    img = np.asarray(img)
+    if img.ndim == 2:
+        return img[:, :, None], True
+    return img, False
+
+
+# ----------------------------------------------------------------------------
+# a1: Gaussian blur  (transformation.py:228-257)  -- OpenCV-backed, parity unpinned
+# ----------------------------------------------------------------------------
+
+def blur_ksize(blur_radius):
+    """Kernel-size rule of apply_blur (transformation.py:239-246).  None => no blur."""
+    ksize = int(blur_radius * 6)
+    if ksize % 2 == 0:
+        ksize += 1
+    if ksize < 3 and blur_radius > 0:
+        ksize = 3
+    elif blur_radius == 0:
+        return None
+    return ksize
+
+
+def gaussian_kernel1d(ksize, sigma):
+    """cv::getGaussianKernel for sigma > 0: exp(-(i-(k-1)/2)^2 / (2 sigma^2)), normalised."""
+    if sigma <= 0:
+        sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    k = np.exp(-(x * x) / (2.0 * sigma * sigma))
+    return k / k.sum()
+
+
+def sepconv_f64(img, kx, ky, index_fn=reflect101_index):
+    """Separable correlation, horizontal then vertical, float64, per channel."""
+    a, was2d = _as3d(img)
+    h, w, _ = a.shape
+    kx = np.asarray(kx, np.float64)
+    ky = np.asarray(ky, np.float64)
+    rx, ry = len(kx) // 2, len(ky) // 2
+    src = a.astype(np.float64)
+    tmp = np.zeros_like(src)
+    xs = np.arange(w)
+    for i, wgt in enumerate(kx):
+        tmp += wgt * src[:, index_fn(xs + i - rx, w), :]
+    out = np.zeros_like(src)
+    ys = np.arange(h)
+    for i, wgt in enumerate(ky):
+        out += wgt * tmp[index_fn(ys + i - ry, h), :, :]
+    return out[:, :, 0] if was2d else out
+
+
+def saturate_u8(v):
+    """cv::saturate_cast<uchar>(double): round half to even, clamp."""
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+def gaussian_blur_f64(img, ksize, sigma):
+    k = gaussian_kernel1d(ksize, sigma)
+    return sepconv_f64(img, k, k)
+
+
+def gaussian_blur(img, ksize, sigma):
+    """cv2.GaussianBlur(img, (ksize, ksize), sigma) by its float definition."""
+    return saturate_u8(gaussian_blur_f64(img, ksize, sigma))
+
+
+def apply_blur(img, blur_radius):
+    """transformation.py:228-257.  The RGB<->BGR swaps (:233,:252) conjugate a
+    per-channel filter and cancel; RGBA input loses alpha (:234-235)."""
+    img = np.asarray(img)
+    ksize = blur_ksize(blur_radius)
+    if ksize is None:
+        return img  # the reference returns the input object itself (:245-246)
+    if img.ndim == 3 and img.shape[2] == 4:
+        img = img[:, :, :3]
+    return gaussian_blur(img, ksize, blur_radius)
+
+
+# ----------------------------------------------------------------------------
+# a5: generic 2-D correlation (cv2.filter2D), motion blur -- parity unpinned
+# ----------------------------------------------------------------------------
+
+def conv2d_f64(img, kernel, index_fn=reflect101_index):
+    a, was2d = _as3d(img)
+    h, w, _ = a.shape
+    kernel = np.asarray(kernel, np.float64)
+    kh, kw = kernel.shape
+    ay, ax = kh // 2, kw // 2  # anchor (-1,-1) => centre
+    src = a.astype(np.float64)
+    out = np.zeros_like(src)
+    ys, xs = np.arange(h), np.arange(w)
+    for j in range(kh):
+        rows = src[index_fn(ys + j - ay, h)]
+        for i in range(kw):
+            if kernel[j, i] != 0.0:
+                out += kernel[j, i] * rows[:, index_fn(xs + i - ax, w), :]
+    return out[:, :, 0] if was2d else out
+
+
+def conv2d(img, kernel):
+    """cv2.filter2D(img, -1, kernel): correlation, centre anchor, REFLECT_101."""
+    return saturate_u8(conv2d_f64(img, kernel))
+
+
+def motion_blur_kernel(size):
+    """cifar_image_transformations.py:113-115."""
+    kernel = np.zeros((size, size))
+    kernel[int((size - 1) / 2), :] = np.ones(size)
+    return kernel / size
+
+
+def motion_blur(img, size):
+    return conv2d(img, motion_blur_kernel(size))
+
+
+def box_kernel(k=3):
+    return np.full((k, k), 1.0 / (k * k))
+
+
+# ----------------------------------------------------------------------------
+# a6: elementwise colour maps
+# ----------------------------------------------------------------------------
+
+def rgb2l(img):
+    """Pillow convert('L') (transformation.py:336): (19595R+38470G+7471B+0x8000)>>16."""
+    a = np.asarray(img).astype(np.uint32)
+    return ((a[..., 0] * 19595 + a[..., 1] * 38470 + a[..., 2] * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def blend(img1, img2, alpha):
+    """Pillow Image.blend (libImaging Blend.c): float32 `in1 + alpha*(in2-in1)`;
+    0<=alpha<=1 truncates, otherwise clips to [0,255] and truncates."""
+    a1 = np.asarray(img1).astype(np.int32)
+    a2 = np.asarray(img2).astype(np.int32)
+    al = np.float32(alpha)
+    t = a1.astype(np.float32) + al * (a2 - a1).astype(np.float32)
+    if 0.0 <= float(al) <= 1.0:
+        return t.astype(np.int32).astype(np.uint8)
+    out = np.where(t <= 0.0, 0, np.where(t >= 255.0, 255, t.astype(np.int32)))
+    return out.astype(np.uint8)
+
+
+def apply_brightness(img, brightness_factor):
+    """transformation.py:261-269: ImageEnhance.Brightness(img).enhance(1+b)
+    = Image.blend(black, img, 1+b)."""
+    img = np.asarray(img)
+    return blend(np.zeros_like(img), img, 1.0 + brightness_factor)
+
+
+def apply_background_change_simple(img, bg_color):
+    """transformation.py:348-354: Image.blend(img, solid(bg), 0.3)."""
+    img = np.asarray(img)
+    bg = np.empty_like(img)
+    bg[...] = np.array([int(c * 255) for c in bg_color], np.uint8)
+    return blend(img, bg, 0.3)
+
+
+def convert_scale_abs(img, alpha, beta=0.0):
+    """cv2.convertScaleAbs: saturate_cast<uchar>(|alpha*p + beta|) (float32 math)."""
+    a = np.asarray(img).astype(np.float32)
+    v = np.abs(a * np.float32(alpha) + np.float32(beta))
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+def apply_contrast(img, contrast_amount):
+    """transformation.py:203-210 (RGBA loses alpha at :205-206)."""
+    img = np.asarray(img)
+    if img.ndim == 3 and img.shape[2] == 4:
+        img = img[:, :, :3]
+    return convert_scale_abs(img, contrast_amount, 0.0)
+
+
+def add_noise(img, noise_f32):
+    """transformation.py:275-278 with the noise tensor given:
+    clip(f32(p)+noise, 0, 255).astype(u8) (truncation)."""
+    a = np.asarray(img).astype(np.float32) + np.asarray(noise_f32, np.float32)
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
+def apply_gaussian_noise(img, noise_std, rng=None):
+    """transformation.py:272-281.  `rng` None => NumPy global MT19937 as the reference."""
+    img = np.asarray(img)
+    gen = np.random if rng is None else rng
+    noise = gen.normal(0, noise_std * 255, img.shape).astype(np.float32)
+    return add_noise(img, noise)
+
+
+def permute_channels(img, perm):
+    """cv2.cvtColor RGB2BGR/BGR2RGB/RGBA2RGB/RGBA2BGR (transformation.py:206,233-235,252)."""
+    return np.ascontiguousarray(np.asarray(img)[..., list(perm)])
+
+
+# ----------------------------------------------------------------------------
+# a2 / a2' / shear: Pillow affine transform (libImaging Geometry.c)
+# ----------------------------------------------------------------------------
+
+def rotate_plan(w, h, angle):
+    """Python layer of Image.rotate(angle) (PIL/Image.py:2509-2568), expand=False,
+    default centre.  Returns ("copy"|"rot180"|"rot90"|"rot270", None) for the fast
+    paths or ("affine", m[6]) with the destination->source matrix."""
+    angle = angle % 360.0
+    if angle == 0:
+        return "copy", None
+    if angle == 180:
+        return "rot180", None
+    if angle in (90, 270) and w == h:
+        return ("rot90" if angle == 90 else "rot270"), None
+    cx, cy = w / 2, h / 2
+    a = -math.radians(angle)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0,
+         round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    m[2] = m[0] * -cx + m[1] * -cy + m[2]
+    m[5] = m[3] * -cx + m[4] * -cy + m[5]
+    m[2] += cx
+    m[5] += cy
+    return "affine", m
+
+
+def rotate_zoom_matrix(w, h, angle_deg, zoom):
+    """Inverse matrix for 'rotate by angle about the centre and zoom by `zoom`'
+    (benchmark configs[3]; SURVEY §8a row a2')."""
+    a = math.radians(angle_deg)
+    c, s = math.cos(a) / zoom, math.sin(a) / zoom
+    cx, cy = w / 2.0, h / 2.0
+    return [c, -s, cx - (c * cx - s * cy), s, c, cy - (s * cx + c * cy)]
+
+
+def _fix16(v):
+    return int(math.floor(v * 65536.0 + 0.5))
+
+
+def _fill_array(oh, ow, c, fill, dtype=np.uint8):
+    out = np.empty((oh, ow, c), dtype)
+    f = np.zeros(c, dtype) if fill is None else np.asarray(list(fill)[:c], dtype)
+    out[...] = f
+    return out
+
+
+def affine_nearest(img, out_size, m, fill=None):
+    """Image.transform(size, AFFINE, m, NEAREST, fillcolor=fill).
+
+    Rotations/shears (m1 or m3 non-zero) go through `affine_fixed` (16.16 fixed
+    point); pure scale/translate matrices go through `ImagingScaleAffine`, which
+    walks the source coordinate by repeated double additions."""
+    a, was2d = _as3d(img)
+    h, w, c = a.shape
+    ow, oh = out_size
+    out = _fill_array(oh, ow, c, fill)
+    if m[1] == 0 and m[3] == 0:
+        # ImagingScaleAffine: xo = a2 + a0*0.5; xo += a0 per pixel; COORD(v) = v<0 ? -1 : (int)v
+        xo = m[2] + m[0] * 0.5
+        xin = np.empty(ow, np.int64)
+        for x in range(ow):
+            xin[x] = -1 if xo < 0.0 else int(xo)
+            xo += m[0]
+        yo = m[5] + m[4] * 0.5
+        yin = np.empty(oh, np.int64)
+        for y in range(oh):
+            yin[y] = -1 if yo < 0.0 else int(yo)
+            yo += m[4]
+        okx = (xin >= 0) & (xin < w)
+        oky = (yin >= 0) & (yin < h)
+        if okx.any() and oky.any():
+            xs = np.nonzero(okx)[0]
+            xmin, xmax = xs[0], xs[-1] + 1  # the C loop copies the whole [xmin,xmax) span
+            ys = np.nonzero(oky)[0]
+            span = np.arange(xmin, xmax)
+            sub = a[yin[ys]][:, np.clip(xin[span], 0, w - 1)]
+            out[np.ix_(ys, span)] = sub
+        return out[:, :, 0] if was2d else out
+    a0, a1, a3, a4 = (_fix16(m[0]), _fix16(m[1]), _fix16(m[3]), _fix16(m[4]))
+    a2 = _fix16(m[2] + 0.5 * m[0] + 0.5 * m[1])
+    a5 = _fix16(m[5] + 0.5 * m[3] + 0.5 * m[4])
+    x = np.arange(ow, dtype=np.int64)[None, :]
+    y = np.arange(oh, dtype=np.int64)[:, None]
+    xin = (a2 + a1 * y + a0 * x) >> 16
+    yin = (a5 + a4 * y + a3 * x) >> 16
+    ok = (xin >= 0) & (xin < w) & (yin >= 0) & (yin < h)
+    src = a[np.clip(yin, 0, h - 1), np.clip(xin, 0, w - 1)]
+    out = np.where(ok[:, :, None], src, out)
+    return out[:, :, 0] if was2d else out
+
+
+def _affine_coords(oh, ow, m):
+    x = np.arange(ow, dtype=np.float64)[None, :] + 0.5
+    y = np.arange(oh, dtype=np.float64)[:, None] + 0.5
+    xin = m[0] * x + m[1] * y + m[2]
+    yin = m[3] * x + m[4] * y + m[5]
+    return xin, yin
+
+
+def affine_bilinear(img, out_size, m, fill=None, return_float=False):
+    """Image.transform(size, AFFINE, m, BILINEAR, fillcolor=fill): float64
+    coordinates and lerps, neighbour clamp, `(UINT8)v` truncation."""
+    a, was2d = _as3d(img)
+    h, w, c = a.shape
+    ow, oh = out_size
+    xin, yin = _affine_coords(oh, ow, m)
+    ok = (xin >= 0.0) & (xin < w) & (yin >= 0.0) & (yin < h)
+    xf = xin - 0.5
+    yf = yin - 0.5
+    x0 = np.floor(xf)
+    y0 = np.floor(yf)
+    dx = (xf - x0)[:, :, None]
+    dy = (yf - y0)[:, :, None]
+    x0 = x0.astype(np.int64)
+    y0 = y0.astype(np.int64)
+    xa = np.clip(x0, 0, w - 1)
+    xb = np.clip(x0 + 1, 0, w - 1)
+    ya = np.clip(y0, 0, h - 1)
+    src = a.astype(np.float64)
+    p00, p01 = src[ya, xa], src[ya, xb]
+    v1 = p00 + (p01 - p00) * dx
+    has_row2 = ((y0 + 1 >= 0) & (y0 + 1 < h))[:, :, None]
+    yb = np.clip(y0 + 1, 0, h - 1)
+    p10, p11 = src[yb, xa], src[yb, xb]
+    v2 = np.where(has_row2, p10 + (p11 - p10) * dx, v1)
+    v = v1 + (v2 - v1) * dy
+    if return_float:
+        fillv = _fill_array(oh, ow, c, fill, np.float64)
+        outf = np.where(ok[:, :, None], v, fillv)
+        return (outf[:, :, 0] if was2d else outf), ok
+    out = _fill_array(oh, ow, c, fill)
+    out = np.where(ok[:, :, None], v.astype(np.int64).astype(np.uint8), out)
+    return out[:, :, 0] if was2d else out
+
+
+def affine_bicubic(img, out_size, m, fill=None, return_float=False):
+    """Image.transform(size, AFFINE, m, BICUBIC, fillcolor=fill)
+    (used by apply_shear, transformation.py:217-224)."""
+    a, was2d = _as3d(img)
+    h, w, c = a.shape
+    ow, oh = out_size
+    xin, yin = _affine_coords(oh, ow, m)
+    ok = (xin >= 0.0) & (xin < w) & (yin >= 0.0) & (yin < h)
+    xf = xin - 0.5
+    yf = yin - 0.5
+    x0 = np.floor(xf)
+    y0 = np.floor(yf)
+    dx = (xf - x0)[:, :, None]
+    dy = (yf - y0)[:, :, None]
+    x0 = x0.astype(np.int64) - 1
+    y0 = y0.astype(np.int64) - 1
+    src = a.astype(np.float64)
+
+    def cubic(v1, v2, v3, v4, d):
+        p1 = v2
+        p2 = -v1 + v3
+        p3 = 2 * (v1 - v2) + v3 - v4
+        p4 = -v1 + v2 - v3 + v4
+        return p1 + d * (p2 + d * (p3 + d * p4))
+
+    xs = [np.clip(x0 + k, 0, w - 1) for k in range(4)]
+
+    def row(yy):
+        yc = np.clip(yy, 0, h - 1)
+        return cubic(src[yc, xs[0]], src[yc, xs[1]], src[yc, xs[2]], src[yc, xs[3]], dx)
+
+    v1 = row(y0)
+    in1 = ((y0 + 1 >= 0) & (y0 + 1 < h))[:, :, None]
+    in2 = ((y0 + 2 >= 0) & (y0 + 2 < h))[:, :, None]
+    in3 = ((y0 + 3 >= 0) & (y0 + 3 < h))[:, :, None]
+    v2 = np.where(in1, row(y0 + 1), v1)
+    v3 = np.where(in2, row(y0 + 2), v2)
+    v4 = np.where(in3, row(y0 + 3), v3)
+    v = cubic(v1, v2, v3, v4, dy)
+    if return_float:
+        fillv = _fill_array(oh, ow, c, fill, np.float64)
+        outf = np.where(ok[:, :, None], v, fillv)
+        return (outf[:, :, 0] if was2d else outf), ok
+    q = np.where(v <= 0.0, 0, np.where(v >= 255.0, 255, v.astype(np.int64))).astype(np.uint8)
+    out = _fill_array(oh, ow, c, fill)
+    out = np.where(ok[:, :, None], q, out)
+    return out[:, :, 0] if was2d else out
+
+
+def apply_rotation(img, angle):
+    """transformation.py:198-201: img.rotate(-angle, fillcolor=(0,0,0), expand=False),
+    default resample NEAREST."""
+    a = np.asarray(img)
+    h, w = a.shape[:2]
+    kind, m = rotate_plan(w, h, -angle)
+    if kind == "copy":
+        return a.copy()
+    if kind == "rot180":
+        return np.ascontiguousarray(a[::-1, ::-1])
+    if kind == "rot90":   # Transpose.ROTATE_90 = counter-clockwise
+        return np.ascontiguousarray(np.rot90(a, 1))
+    if kind == "rot270":
+        return np.ascontiguousarray(np.rot90(a, 3))
+    return affine_nearest(a, (w, h), m, fill=(0, 0, 0))
+
+
+def rotate_bilinear(img, angle):
+    """img.rotate(angle, resample=BILINEAR, fillcolor=0) — the benchmark variant."""
+    a = np.asarray(img)
+    h, w = a.shape[:2]
+    kind, m = rotate_plan(w, h, angle)
+    if kind != "affine":
+        return apply_rotation(a, -angle)
+    return affine_bilinear(a, (w, h), m, fill=(0, 0, 0))
+
+
+def shear_geometry(w, h, shear_factor):
+    """transformation.py:213-221 -> (new_width, matrix)."""
+    shift = int(math.ceil(shear_factor * h))
+    m = (1, shear_factor, -shift if shear_factor > 0 else 0, 0, 1, 0)
+    return w + shift, m
+
+
+def apply_shear(img, shear_factor):
+    """transformation.py:212-226: BICUBIC affine, white fill, widened output."""
+    a = np.asarray(img)
+    h, w = a.shape[:2]
+    nw, m = shear_geometry(w, h, shear_factor)
+    return affine_bicubic(a, (nw, h), [float(v) for v in m], fill=(255, 255, 255))
+
+
+# ----------------------------------------------------------------------------
+# a3: Lanczos resize (libImaging Resample.c), apply_scale
+# ----------------------------------------------------------------------------
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _lanczos3(x):
+    if -3.0 <= x < 3.0:
+        def sinc(t):
+            if t == 0.0:
+                return 1.0
+            t = t * math.pi
+            return math.sin(t) / t
+        return sinc(x) * sinc(x / 3)
+    return 0.0
+
+
+def lanczos_coeffs(in_size, out_size):
+    """precompute_coeffs + normalize_coeffs_8bpc for the whole-image box.
+    Returns (bounds[out,2] int32 (xmin, count), kk[out,ksize] int32, ksize)."""
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 3.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        ws = [_lanczos3((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in ws:
+            ww += v
+        for x in range(xmax):
+            v = ws[x] / ww if ww != 0.0 else ws[x]
+            if v < 0:
+                kk[xx, x] = int(-0.5 + v * (1 << PRECISION_BITS))
+            else:
+                kk[xx, x] = int(0.5 + v * (1 << PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+def _resample_axis0(a, out_size):
+    """Resample along axis 0 of an (n, m, c) uint8 array."""
+    n = a.shape[0]
+    bounds, kk, ksize = lanczos_coeffs(n, out_size)
+    src = a.astype(np.int64)
+    acc = np.full((out_size,) + a.shape[1:], 1 << (PRECISION_BITS - 1), np.int64)
+    idx = bounds[:, 0][:, None] + np.arange(ksize)[None, :]
+    idx = np.minimum(idx, n - 1)  # coefficients beyond count are zero
+    for t in range(ksize):
+        acc += src[idx[:, t]] * kk[:, t].astype(np.int64)[:, None, None]
+    return np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
+
+
+def resize_lanczos(img, size):
+    """img.resize(size, LANCZOS): horizontal pass, uint8 intermediate, vertical pass;
+    a pass is skipped when that dimension is unchanged (Resample.c ImagingResample)."""
+    a, was2d = _as3d(img)
+    h, w, _ = a.shape
+    nw, nh = size
+    out = a
+    if nw != w:
+        out = np.ascontiguousarray(_resample_axis0(out.transpose(1, 0, 2), nw).transpose(1, 0, 2))
+    if nh != h:
+        out = _resample_axis0(out, nh)
+    out = np.ascontiguousarray(out) if out is not a else a.copy()
+    return out[:, :, 0] if was2d else out
+
+
+def scale_geometry(w, h, scale_factor):
+    """transformation.py:174-194 -> (nw, nh, mode, ox, oy) with mode in crop|paste|none."""
+    nw = int(w * scale_factor)
+    nh = int(h * scale_factor)
+    if scale_factor > 1.0:
+        return nw, nh, "crop", (nw - w) // 2, (nh - h) // 2
+    if scale_factor < 1.0:
+        return nw, nh, "paste", (w - nw) // 2, (h - nh) // 2
+    return nw, nh, "none", 0, 0
+
+
+def apply_scale(img, scale_factor):
+    """transformation.py:173-196."""
+    a = np.asarray(img)
+    h, w = a.shape[:2]
+    nw, nh, mode, ox, oy = scale_geometry(w, h, scale_factor)
+    scaled = resize_lanczos(a, (nw, nh))
+    if mode == "crop":
+        return np.ascontiguousarray(scaled[oy:oy + h, ox:ox + w])
+    if mode == "paste":
+        out = np.zeros_like(a)
+        out[oy:oy + nh, ox:ox + nw] = scaled
+        return out
+    return scaled
+
+
+def apply_camera_distance(img, distance_factor):
+    """transformation.py:309-314."""
+    return apply_scale(img, 2.75 / distance_factor)
+
+
+# ----------------------------------------------------------------------------
+# translation (transformation.py:284-307)
+# ----------------------------------------------------------------------------
+
+def apply_translation(img, tx, ty):
+    a = np.asarray(img)
+    h, w = a.shape[:2]
+    out = np.zeros_like(a)
+    px, py = int(tx), int(ty)
+    cl, ct = max(0, -px), max(0, -py)
+    cr, cb = min(w, w - px), min(h, h - py)
+    if cl < cr and ct < cb:
+        rx, ry = max(0, px), max(0, py)
+        out[ry:ry + (cb - ct), rx:rx + (cr - cl)] = a[ct:cb, cl:cr]
+    return out
+
+
+def apply_xy_translation_3d(img, tx, ty):
+    """transformation.py:316-321."""
+    a = np.asarray(img)
+    h, w = a.shape[:2]
+    return apply_translation(a, int(tx * w), int(ty * h))
+
+
+# ----------------------------------------------------------------------------
+# a4: Sobel + background change (transformation.py:328-345)
+# ----------------------------------------------------------------------------
+
+def sobel_scipy(gray, axis=-1):
+    """scipy.ndimage.sobel(uint8 array, axis) with uint8 output: derivative
+    [-1,0,1] along `axis`, smoothing [1,2,1] along the other, mode 'reflect',
+    result stored mod 256."""
+    g = np.asarray(gray).astype(np.int64)
+    h, w = g.shape
+    axis = axis % 2
+    ys, xs = np.arange(h), np.arange(w)
+
+    def shift(arr, d, ax):
+        if ax == 0:
+            return arr[reflect_index(ys + d, h), :]
+        return arr[:, reflect_index(xs + d, w)]
+
+    d = shift(g, 1, axis) - shift(g, -1, axis)
+    o = 1 - axis
+    s = shift(d, -1, o) + 2 * d + shift(d, 1, o)
+    return np.mod(s, 256).astype(np.uint8)
+
+
+def sobel_gradients(gray):
+    """Exact integer Gx, Gy (no wrap) with SciPy 'reflect' borders."""
+    g = np.asarray(gray).astype(np.int64)
+    h, w = g.shape
+    ys, xs = np.arange(h), np.arange(w)
+    up, dn = g[reflect_index(ys - 1, h), :], g[reflect_index(ys + 1, h), :]
+    lf, rt = g[:, reflect_index(xs - 1, w)], g[:, reflect_index(xs + 1, w)]
+    dxv = rt - lf
+    gx = dxv[reflect_index(ys - 1, h), :] + 2 * dxv + dxv[reflect_index(ys + 1, h), :]
+    dyv = dn - up
+    gy = dyv[:, reflect_index(xs - 1, w)] + 2 * dyv + dyv[:, reflect_index(xs + 1, w)]
+    return gx, gy
+
+
+def sobel_magnitude_f(gray):
+    gx, gy = sobel_gradients(gray)
+    return np.sqrt((gx * gx + gy * gy).astype(np.float64))
+
+
+def sobel_magnitude(gray):
+    """Benchmark configs[2]: sqrt(Gx^2+Gy^2) on the L image, saturate-round to uint8.
+    No reference counterpart; defined by this oracle."""
+    return saturate_u8(sobel_magnitude_f(gray))
+
+
+def rgb_sobel_magnitude(img):
+    return sobel_magnitude(rgb2l(img))
+
+
+def percentile_linear_u8(values_u8, q):
+    """np.percentile(uint8 array, q) (default 'linear' method) from a histogram."""
+    v = np.asarray(values_u8).ravel()
+    n = v.size
+    hist = np.bincount(v, minlength=256)
+    cum = np.cumsum(hist)
+    quant = q / 100.0
+    # numpy _compute_virtual_index with alpha = beta = 1
+    virt = n * quant + (1.0 + quant * (1.0 - 1.0 - 1.0)) - 1.0
+    lo = int(math.floor(virt))
+    gamma = virt - lo
+    lo = min(max(lo, 0), n - 1)
+    hi = min(lo + 1, n - 1)
+    a = float(np.searchsorted(cum, lo, side="right"))
+    b = float(np.searchsorted(cum, hi, side="right"))
+    # numpy _lerp
+    diff = b - a
+    out = a + diff * gamma
+    if gamma >= 0.5:
+        out = b - diff * (1.0 - gamma)
+    if diff == 0:
+        out = a
+    return out
+
+
+def binary_dilation_cross(mask, iterations=1):
+    """scipy.ndimage.binary_dilation(mask, iterations=k): 4-connected cross,
+    border value 0."""
+    m = np.asarray(mask, bool)
+    for _ in range(iterations):
+        p = np.pad(m, 1)
+        m = p[1:-1, 1:-1] | p[:-2, 1:-1] | p[2:, 1:-1] | p[1:-1, :-2] | p[1:-1, 2:]
+    return m
+
+
+def composite(img1, img2, mask_u8):
+    """Image.composite(img1, img2, mask) for an L mask holding only 0/255."""
+    m = np.asarray(mask_u8) != 0
+    return np.where(m[:, :, None], np.asarray(img1), np.asarray(img2))
+
+
+def apply_background_change(img, bg_color):
+    """transformation.py:328-345."""
+    a = np.asarray(img)
+    if a.shape[2] == 4:
+        a = a[:, :, :3]
+    bg = np.empty_like(a)
+    bg[...] = np.array([int(c * 255) for c in bg_color], np.uint8)
+    gray = rgb2l(a)
+    edges = sobel_scipy(gray)
+    thr = percentile_linear_u8(edges, 70)
+    fg = binary_dilation_cross(edges > thr, 3)
+    return composite(a, bg, (fg * 255).astype(np.uint8))
+
+
+# ----------------------------------------------------------------------------
+# benchmark configs[0]: grayscale + 3x3 box blur
+# ----------------------------------------------------------------------------
+
+def gray_box3(img):
+    return conv2d(rgb2l(img), box_kernel(3))
+
+
+# ----------------------------------------------------------------------------
+# H: driver value grids (transformation.py:95-105,125-139)
+# ----------------------------------------------------------------------------
+
+TRANSFORM_GRID = {
+    "scale": (0.9, 1.4, 0.1),
+    "rotation": (-22.5, 22.5, 2.5),
+    "lighten_darken": (-0.05, 0.05, 0.01),
+    "gaussian_noise": (0.0, 0.1, 0.01),
+    "translation": (-50, 50, 5),
+    "contrast": (0, 1, 0.1),
+    "blur": (0, 5, 0.5),
+    "shear": (0, 1, 0.1),
+}
+
+
+def grid_values(name):
+    lo, hi, step = TRANSFORM_GRID[name]
+    num_steps = int((hi - lo) / step) + 1
+    return [lo + j * step for j in range(num_steps)]

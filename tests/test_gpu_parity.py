@@ -1,0 +1,308 @@
+"""GPU parity: every libimgxf kernel, called through the C-ABI (ctypes), against the CPU
+oracle on the same seeded inputs.  Integer / nearest-neighbour ops must be bit-exact;
+Gaussian and fp32 bilinear are checked on the pre-quantisation fp32 value to 1e-5 relative
+(BASELINE.json north_star) and the uint8 output may differ by 1 only where the oracle's
+float value sits within that tolerance of a rounding/truncation boundary."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth
+from oracle import imgxf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(32, 32), (37, 61), (48, 64), (334, 500), (270, 480)]   # (h, w); 480*3 is 16-B aligned
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def assert_quantised_close(got_u8, got_f32, ref_f64, quantise, rel=1e-5):
+    """got_f32 within rel of ref; got_u8 == quantise(ref) except at boundary ties."""
+    ref = np.asarray(ref_f64, np.float64)
+    tol = rel * np.maximum(np.abs(ref), 1.0)
+    err = np.abs(got_f32.astype(np.float64) - ref)
+    assert (err <= tol).all(), f"max err {err.max()} (rel {rel})"
+    want = quantise(ref)
+    diff = got_u8.astype(np.int32) - want.astype(np.int32)
+    bad = diff != 0
+    if bad.any():
+        assert np.abs(diff[bad]).max() == 1
+        # every mismatch must be explained by the tolerance: quantising ref +- tol flips it
+        lo, hi = quantise(ref - tol), quantise(ref + tol)
+        assert ((got_u8 == lo) | (got_u8 == hi))[bad].all()
+        assert bad.mean() < 1e-3
+
+
+# ------------------------------------------------------------------ a1 Gaussian
+@pytest.mark.parametrize("hw", SIZES)
+@pytest.mark.parametrize("radius", [0.5, 5 / 6, 1.0, 1.5, 2.5, 5.0])
+def test_gaussian_rgb(device, hw, radius):
+    from imagetransformations_amd import ops
+    a = synth(11, *hw)
+    k = O.blur_ksize(radius)
+    out, f32 = ops.gaussian_blur(dev(a, device), k, radius, return_f32=True)
+    ref = O.gaussian_blur_f64(a, k, radius)
+    assert_quantised_close(host(out), host(f32), ref, O.saturate_u8)
+
+
+@pytest.mark.parametrize("c", [1, 4])
+def test_gaussian_other_channel_counts(device, c):
+    from imagetransformations_amd import ops
+    a = synth(12, 45, 67, c)
+    out, f32 = ops.gaussian_blur(dev(a, device), 7, 1.0, return_f32=True)
+    assert_quantised_close(host(out), host(f32), O.gaussian_blur_f64(a, 7, 1.0), O.saturate_u8)
+
+
+def test_gaussian_batch_and_strided_views(device):
+    from imagetransformations_amd import ops
+    batch = np.stack([synth(20 + i, 40, 48) for i in range(3)])
+    out = host(ops.gaussian_blur(dev(batch, device), 5, 5 / 6))
+    for i in range(3):
+        ref = O.gaussian_blur(batch[i], 5, 5 / 6)
+        assert np.abs(out[i].astype(int) - ref.astype(int)).max() <= 1
+        assert (out[i] != ref).mean() < 1e-3
+    # non-contiguous frame stride: every other frame of a larger batch
+    big = dev(np.stack([synth(30 + i, 40, 48) for i in range(4)]), device)
+    sub = big[::2]
+    out2 = host(ops.gaussian_blur(sub, 5, 5 / 6))
+    assert np.array_equal(out2[1], host(ops.gaussian_blur(big[2], 5, 5 / 6)))
+
+
+def test_gaussian_tiny_images(device):
+    from imagetransformations_amd import ops
+    for hw in [(1, 1), (1, 7), (5, 1), (2, 2), (3, 5)]:
+        a = synth(13, *hw)
+        out, f32 = ops.gaussian_blur(dev(a, device), 7, 1.0, return_f32=True)
+        assert_quantised_close(host(out), host(f32), O.gaussian_blur_f64(a, 7, 1.0), O.saturate_u8)
+
+
+def test_gaussian_rejects_bad_arguments(device):
+    from imagetransformations_amd import ops
+    t = dev(synth(1, 8, 8), device)
+    with pytest.raises(ValueError):
+        ops.gaussian_blur(t, 4, 1.0)        # even ksize
+    with pytest.raises(ValueError):
+        ops.gaussian_blur(t, 33, 1.0)       # too large
+    with pytest.raises(ValueError):
+        ops.gaussian_blur(t.cpu(), 3, 1.0)  # host tensor: no CPU path
+
+
+# ------------------------------------------------------------------ a5 conv2d / motion blur
+@pytest.mark.parametrize("size", [5, 7, 9, 11])
+def test_motion_blur(device, size):
+    from imagetransformations_amd import ops
+    a = synth(14, 32, 32)
+    out = host(ops.conv2d(dev(a, device), O.motion_blur_kernel(size)))
+    ref_f = O.conv2d_f64(a, O.motion_blur_kernel(size))
+    ref = O.saturate_u8(ref_f)
+    diff = np.abs(out.astype(int) - ref.astype(int))
+    assert diff.max() <= 1
+    near_tie = np.abs(ref_f - np.floor(ref_f) - 0.5) < 1e-4
+    assert (diff == 0)[~near_tie].all()
+
+
+def test_gray_box3_config0(device):
+    """BASELINE configs[0]: grayscale + 3x3 box blur on 512x512 RGB."""
+    from imagetransformations_amd import ops
+    a = synth(15, 512, 512)
+    gray = ops.rgb2l(dev(a, device))
+    out = host(ops.conv2d(gray, O.box_kernel(3)))
+    ref_f = O.conv2d_f64(O.rgb2l(a), O.box_kernel(3))
+    diff = np.abs(out.astype(int) - O.saturate_u8(ref_f).astype(int))
+    near_tie = np.abs(ref_f - np.floor(ref_f) - 0.5) < 1e-4
+    assert diff.max() <= 1 and (diff == 0)[~near_tie].all()
+
+
+# ------------------------------------------------------------------ a4 Sobel
+@pytest.mark.parametrize("hw", SIZES + [(1, 9), (9, 1)])
+def test_sobel_variants_bit_exact(device, hw):
+    from imagetransformations_amd import ops, _ffi
+    g = synth(16, *hw, c=1)
+    t = dev(g, device)
+    assert np.array_equal(host(ops.sobel(t, _ffi.SOBEL_X_WRAP)), O.sobel_scipy(g, -1))
+    assert np.array_equal(host(ops.sobel(t, _ffi.SOBEL_Y_WRAP)), O.sobel_scipy(g, 0))
+    assert np.array_equal(host(ops.sobel(t, _ffi.SOBEL_MAGNITUDE)), O.sobel_magnitude(g))
+
+
+@pytest.mark.parametrize("hw", [(37, 61), (334, 500)])
+def test_rgb_sobel_magnitude_fused(device, hw):
+    from imagetransformations_amd import ops
+    a = synth(17, *hw)
+    assert np.array_equal(host(ops.rgb_sobel_magnitude(dev(a, device))), O.rgb_sobel_magnitude(a))
+
+
+# ------------------------------------------------------------------ a2 affine
+@pytest.mark.parametrize("hw", SIZES)
+@pytest.mark.parametrize("angle", [-22.5, -2.5, 0.0, 10.0, 22.5, 30.0, 90.0, 180.0, 270.0])
+def test_rotation_nearest_bit_exact(device, hw, angle):
+    from imagetransformations_amd import ops
+    a = synth(18, *hw)
+    out = host(ops.rotate(dev(a, device), -angle, ops.NEAREST, fillcolor=(0, 0, 0)))
+    assert np.array_equal(out, O.apply_rotation(a, angle))
+
+
+@pytest.mark.parametrize("hw", SIZES)
+def test_affine_bilinear_precise_bit_exact(device, hw):
+    from imagetransformations_amd import ops
+    a = synth(19, *hw)
+    h, w = hw
+    for m in (O.rotate_zoom_matrix(w, h, 30.0, 1.5), O.rotate_plan(w, h, 7.0)[1]):
+        out = host(ops.affine(dev(a, device), m, (w, h), ops.BILINEAR, (0, 0, 0), precise=True))
+        assert np.array_equal(out, O.affine_bilinear(a, (w, h), m, fill=(0, 0, 0)))
+
+
+@pytest.mark.parametrize("hw", SIZES)
+def test_affine_bilinear_fast_within_tolerance(device, hw):
+    from imagetransformations_amd import ops
+    a = synth(19, *hw)
+    h, w = hw
+    m = O.rotate_zoom_matrix(w, h, 30.0, 1.5)
+    out, f32 = ops.affine(dev(a, device), m, (w, h), ops.BILINEAR, (0, 0, 0), precise=False, return_f32=True)
+    ref_f, ok = O.affine_bilinear(a, (w, h), m, fill=(0, 0, 0), return_float=True)
+    assert_quantised_close(host(out), host(f32), ref_f, lambda v: np.clip(v, 0, 255).astype(np.int64).astype(np.uint8))
+
+
+@pytest.mark.parametrize("hw", SIZES)
+@pytest.mark.parametrize("shear", [0.0, 0.1, 0.30000000000000004, 0.6000000000000001, 1.0])
+def test_shear_bicubic_bit_exact(device, hw, shear):
+    from imagetransformations_amd import ops
+    a = synth(21, *hw)
+    h, w = hw
+    nw, m = O.shear_geometry(w, h, shear)
+    out = host(ops.affine(dev(a, device), m, (nw, h), ops.BICUBIC, (255, 255, 255), precise=True))
+    assert np.array_equal(out, O.apply_shear(a, shear))
+
+
+def test_affine_gray_and_output_size(device):
+    from imagetransformations_amd import ops
+    g = synth(22, 40, 50, c=1)
+    m = O.rotate_zoom_matrix(50, 40, -17.0, 0.8)
+    for flt, fn in ((ops.NEAREST, O.affine_nearest), (ops.BILINEAR, O.affine_bilinear), (ops.BICUBIC, O.affine_bicubic)):
+        out = host(ops.affine(dev(g, device), m, (63, 29), flt, (7,), precise=True))
+        assert np.array_equal(out, fn(g, (63, 29), m, fill=(7,)))
+
+
+@pytest.mark.parametrize("m", [(1, 0, 3.3, 0, 1, -2.7), (0.7, 0, -3, 0, 1.3, 5), (1.5, 0, 10.2, 0, 0.5, 0.3),
+                               (1, 0, 1000, 0, 1, 0)])
+def test_affine_scale_nearest_bit_exact(device, m):
+    from imagetransformations_amd import ops
+    a = synth(23, 37, 61)
+    out = host(ops.affine(dev(a, device), m, (66, 34), ops.NEAREST, (9, 8, 7)))
+    assert np.array_equal(out, O.affine_nearest(a, (66, 34), [float(v) for v in m], fill=(9, 8, 7)))
+
+
+# ------------------------------------------------------------------ a3 Lanczos
+@pytest.mark.parametrize("hw", SIZES)
+@pytest.mark.parametrize("s", [0.9, 1.0, 1.1, 1.2000000000000002, 1.3, 1.5, 0.33])
+def test_scale_lanczos_bit_exact(device, hw, s):
+    from imagetransformations_amd import ops
+    a = synth(24, *hw)
+    h, w = hw
+    nw, nh = int(w * s), int(h * s)
+    out = host(ops.resize_lanczos(dev(a, device), (nw, nh)))
+    assert np.array_equal(out, O.resize_lanczos(a, (nw, nh)))
+
+
+def test_resize_lanczos_anisotropic_and_batch(device):
+    from imagetransformations_amd import ops
+    batch = np.stack([synth(25 + i, 40, 48) for i in range(3)])
+    for size in [(48, 80), (31, 40), (70, 17)]:
+        out = host(ops.resize_lanczos(dev(batch, device), size))
+        for i in range(3):
+            assert np.array_equal(out[i], O.resize_lanczos(batch[i], size))
+
+
+# ------------------------------------------------------------------ a6 colour maps
+@pytest.mark.parametrize("hw", SIZES)
+def test_pointwise_bit_exact(device, hw):
+    from imagetransformations_amd import ops
+    a = synth(26, *hw)
+    t = dev(a, device)
+    assert np.array_equal(host(ops.rgb2l(t)), O.rgb2l(a))
+    for b in O.grid_values("lighten_darken") + [0.5, -0.5, 1.0]:
+        assert np.array_equal(host(ops.brightness(t, 1.0 + b)), O.apply_brightness(a, b)), b
+    for alpha in O.grid_values("contrast") + [1.7, -0.4]:
+        assert np.array_equal(host(ops.scale_abs(t, alpha, 0.0)), O.convert_scale_abs(a, alpha)), alpha
+    assert np.array_equal(host(ops.blend(t, (51, 127, 229), 0.3)), O.apply_background_change_simple(a, (0.2, 0.5, 0.9)))
+    b2 = synth(27, *hw)
+    for alpha in (0.0, 0.25, 1.0, 1.5, -0.5):
+        assert np.array_equal(host(ops.blend(t, dev(b2, device), alpha)), O.blend(a, b2, alpha)), alpha
+    noise = np.random.default_rng(5).normal(0, 0.05 * 255, a.shape).astype(np.float32)
+    assert np.array_equal(host(ops.add_noise(t, dev(noise, device))), O.add_noise(a, noise))
+    assert np.array_equal(host(ops.permute_channels(t, (2, 1, 0))), O.permute_channels(a, (2, 1, 0)))
+    rgba = synth(28, *hw, c=4)
+    assert np.array_equal(host(ops.permute_channels(dev(rgba, device), (0, 1, 2))), rgba[..., :3])
+    assert np.array_equal(host(ops.rgb2l(dev(rgba, device))), O.rgb2l(rgba))
+
+
+def test_geometry_ops(device):
+    from imagetransformations_amd import ops
+    a = synth(29, 37, 61)
+    t = dev(a, device)
+    assert np.array_equal(host(ops.crop(t, (5, 3, 50, 30))), a[3:30, 5:50])
+    canvas = ops.new(t, 50, 70, (1, 2, 3))
+    ops.copy_rect(t, canvas, 0, 0, 4, 6, 61, 37)
+    ref = np.empty((50, 70, 3), np.uint8); ref[...] = (1, 2, 3); ref[6:43, 4:65] = a
+    assert np.array_equal(host(canvas), ref)
+    for k in (1, 2, 3):
+        assert np.array_equal(host(ops.rot90(t, k)), np.rot90(a, k))
+
+
+# ------------------------------------------------------------------ mask stage
+@pytest.mark.parametrize("hw", [(32, 32), (37, 61), (334, 500)])
+def test_background_mask_stage(device, hw):
+    from imagetransformations_amd import ops
+    a = synth(31, *hw)
+    edges = O.sobel_scipy(O.rgb2l(a))
+    et = dev(edges, device)
+    for q in (70, 50, 1, 99, 33.3):
+        mask, thr = ops.percentile_mask(et, q, return_threshold=True)
+        want = O.percentile_linear_u8(edges, q)
+        assert float(thr.cpu()[0]) == want
+        assert np.array_equal(host(mask), ((edges > want) * 255).astype(np.uint8))
+    mask = (edges > O.percentile_linear_u8(edges, 70))
+    for it in (1, 3, 5):
+        got = host(ops.dilate_cross(dev((mask * 255).astype(np.uint8), device), it))
+        assert np.array_equal(got, (O.binary_dilation_cross(mask, it) * 255).astype(np.uint8))
+    bg = np.empty_like(a); bg[...] = (10, 200, 30)
+    fg = (O.binary_dilation_cross(mask, 3) * 255).astype(np.uint8)
+    assert np.array_equal(host(ops.composite(dev(a, device), dev(bg, device), dev(fg, device))), O.composite(a, bg, fg))
+
+
+# ------------------------------------------------------------------ full sizes (properties + checksums)
+def test_full_size_4k_properties(device):
+    """At BASELINE's full size: the integer ops against the oracle directly (numpy handles 4K
+    in seconds), Gaussian through size-independent properties."""
+    from imagetransformations_amd import ops
+    a = synth(12345, 2160, 3840)
+    t = dev(a, device)
+    # nearest rotation: bit-exact at 4K
+    assert np.array_equal(host(ops.rotate(t, -30.0, ops.NEAREST, (0, 0, 0))), O.apply_rotation(a, 30.0))
+    # Gaussian: constant image is a fixed point; mean is preserved to rounding; batch == single
+    const = torch.full((2160, 3840, 3), 77, dtype=torch.uint8, device=device)
+    assert bool((ops.gaussian_blur(const, 5, 5 / 6) == 77).all())
+    g = ops.gaussian_blur(t, 5, 5 / 6)
+    assert abs(float(g.float().mean()) - float(t.float().mean())) < 0.05
+    # interior linearity probe: blur(a) on a 64x64 crop interior equals the oracle on the crop
+    crop = a[1000:1064, 2000:2064]
+    ref = O.gaussian_blur(crop, 5, 5 / 6)[2:-2, 2:-2]
+    got = host(g)[1002:1062, 2002:2062]
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and (got != ref).mean() < 1e-3
+    # borders against the oracle on edge strips
+    top = O.gaussian_blur(a[:8], 5, 5 / 6)[:4]
+    assert np.abs(host(g)[:4].astype(int) - top.astype(int)).max() <= 1
+    left = O.gaussian_blur(a[:, :8], 5, 5 / 6)[:, :4]
+    assert np.abs(host(g)[:, :4].astype(int) - left.astype(int)).max() <= 1
+    right = O.gaussian_blur(a[:, -8:], 5, 5 / 6)[:, -4:]
+    assert np.abs(host(g)[:, -4:].astype(int) - right.astype(int)).max() <= 1
+    # bilinear rotate+zoom, precise mode: bit-exact against the oracle at 4K
+    m = O.rotate_zoom_matrix(3840, 2160, 30.0, 1.5)
+    got = host(ops.affine(t, m, (3840, 2160), ops.BILINEAR, (0, 0, 0), precise=True))
+    assert np.array_equal(got, O.affine_bilinear(a, (3840, 2160), m, fill=(0, 0, 0)))
