@@ -21,6 +21,9 @@ OBJ = CSRC / "_obj"
 LIB = PKG / "libimgxf.so"
 ARCH = "gfx950"
 FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-fvisibility=hidden",
+         # IEEE sequencing everywhere: Pillow/NumPy parity needs un-fused mul+add; kernels that
+         # want an FMA say fmaf() explicitly.
+         "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
@@ -41,6 +44,10 @@ def build_library(force: bool = False, verbose: bool = True, jobs: int | None = 
     OBJ.mkdir(exist_ok=True)
     sources = sorted(CSRC.glob("*.hip"))
     hdr_time = _newest_header()
+    stamp = OBJ / "flags.txt"
+    if not stamp.exists() or stamp.read_text() != " ".join(FLAGS):
+        force = True
+        stamp.write_text(" ".join(FLAGS))
     todo = []
     objs = []
     for src in sources:

@@ -27,7 +27,7 @@ struct PreciseArith {
     static __device__ __forceinline__ T add(T a, T b) { return __dadd_rn(a, b); }
     static __device__ __forceinline__ T sub(T a, T b) { return __dsub_rn(a, b); }
 };
-// Fast: fp32, contraction allowed (<= 1e-5 relative before truncation).
+// Fast: fp32 (<= 1e-5 relative before truncation).
 struct FastArith {
     typedef float T;
     static __device__ __forceinline__ T mul(T a, T b) { return a * b; }
@@ -35,9 +35,16 @@ struct FastArith {
     static __device__ __forceinline__ T sub(T a, T b) { return a - b; }
 };
 
+// BILINEAR(v,a,b,d) = a + (b-a)*d
+__device__ __forceinline__ double lerp_t(PreciseArith, double a, double b, double d) {
+    return a + (b - a) * d;          // built with -ffp-contract=off: two roundings, as in C on x86-64
+}
+__device__ __forceinline__ float lerp_t(FastArith, float a, float b, float d) {
+    return fmaf(b - a, d, a);
+}
 template <class A>
 __device__ __forceinline__ typename A::T lerp(typename A::T a, typename A::T b, typename A::T d) {
-    return A::add(a, A::mul(A::sub(b, a), d));   // BILINEAR(v,a,b,d) = a + (b-a)*d
+    return lerp_t(A(), a, b, d);
 }
 
 template <class A>
