@@ -5,9 +5,9 @@
 #include <string.h>
 
 namespace imgxf {
-int sepconv_tile_c1(int R, const View&, const View&, const View&, const Taps&, int, hipStream_t);
-int sepconv_tile_c3(int R, const View&, const View&, const View&, const Taps&, int, hipStream_t);
-int sepconv_tile_c4(int R, const View&, const View&, const View&, const Taps&, int, hipStream_t);
+int sepconv_c1(int R, const View&, const View&, const View&, const Taps&, int, hipStream_t);
+int sepconv_c3(int R, const View&, const View&, const View&, const Taps&, int, hipStream_t);
+int sepconv_c4(int R, const View&, const View&, const View&, const Taps&, int, hipStream_t);
 
 static int run_sepconv(const imgxf_view* src, const imgxf_view* dst, const float* kx, int nkx,
                        const float* ky, int nky, int border, const imgxf_view* dst_f32,
@@ -35,9 +35,9 @@ static int run_sepconv(const imgxf_view* src, const imgxf_view* dst, const float
     const View s = make_view(src), d = make_view(dst);
     hipStream_t st = (hipStream_t)stream;
     switch (src->c) {
-        case 1: return sepconv_tile_c1(R, s, d, df, taps, border, st);
-        case 3: return sepconv_tile_c3(R, s, d, df, taps, border, st);
-        case 4: return sepconv_tile_c4(R, s, d, df, taps, border, st);
+        case 1: return sepconv_c1(R, s, d, df, taps, border, st);
+        case 3: return sepconv_c3(R, s, d, df, taps, border, st);
+        case 4: return sepconv_c4(R, s, d, df, taps, border, st);
         default: return IMGXF_ERR_UNSUPPORTED;
     }
 }

@@ -1,8 +1,21 @@
-// sepconv tile kernels for C=1 interleaved channels (see sepconv_tile.inc).
-#include "sepconv_tile.inc"
+// sepconv kernels for C=1 interleaved channels: register-marching fast path
+// (sepconv_march.inc) when rows are 16-byte aligned and the halo fits one block,
+// LDS-tiled general path (sepconv_tile.inc) otherwise.
+#include "sepconv_march.inc"
+#include <stdlib.h>
 namespace imgxf {
-int sepconv_tile_c1(int R, const View& s, const View& d, const View& df, const Taps& taps,
-                    int border, hipStream_t st) {
+int sepconv_c1(int R, const View& s, const View& d, const View& df, const Taps& taps,
+               int border, hipStream_t st) {
+    static const int rpw_env = getenv("IMGXF_MARCH_RPW") ? atoi(getenv("IMGXF_MARCH_RPW")) : 0;
+    static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
+    if (!no_march && march_eligible(s, d, df, 1, R, border)) {
+        switch (R) {
+#define IMGXF_M(r) case r: return launch_sepconv_march<1, r>(s, d, df, taps, st, rpw_env);
+            IMGXF_M(1) IMGXF_M(2) IMGXF_M(3) IMGXF_M(4) IMGXF_M(5)
+#undef IMGXF_M
+            default: break;
+        }
+    }
     return dispatch_sepconv_tile<1>(R, s, d, df, taps, border, st);
 }
 } // namespace imgxf

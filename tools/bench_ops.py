@@ -1,0 +1,52 @@
+"""Quick per-op timing on one GPU (development aid; bench.py is the contract benchmark).
+usage: python tools/bench_ops.py [gauss|affine|affine_fast|sobel|point|all] [frames]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from imagetransformations_amd import ops, _ffi
+
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+H, W = 2160, 3840
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(1)
+frames = torch.randint(0, 256, (F, H, W, 3), dtype=torch.uint8, device=dev, generator=g)
+out = torch.empty_like(frames)
+st = torch.cuda.current_stream().cuda_stream
+vs, vo = _ffi.view_of(frames), _ffi.view_of(out)
+
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+px = F * H * W
+def report(name, ms, bpp):
+    print(f"{name:34s} {ms:8.3f} ms  {px/ms/1e3:10.0f} Mpix/s  {bpp*px/ms/1e6:8.1f} GB/s  {bpp*px/ms/1e6/8000*100:5.1f}% of 8 TB/s", flush=True)
+
+if what in ("gauss", "all"):
+    for k, s in ((5, 5/6), (3, 0.5), (7, 1.0), (9, 1.5)):
+        report(f"gaussian k={k}", timeit(lambda: _ffi.call("imgxf_gaussian_u8", _ffi.vp(vs), _ffi.vp(vo), k, s, None, st)), 6.0)
+if what in ("gauss_big", "all"):
+    for k, s in ((13, 2.0), (31, 5.0)):
+        report(f"gaussian k={k}", timeit(lambda: _ffi.call("imgxf_gaussian_u8", _ffi.vp(vs), _ffi.vp(vo), k, s, None, st), 3), 6.0)
+m = _ffi.f64_array(ops.rotate_zoom_matrix(W, H, 30.0, 1.5)); fill = _ffi.u8_array([0, 0, 0])
+if what in ("affine", "all"):
+    report("rot30+1.5x bilinear precise", timeit(lambda: _ffi.call("imgxf_affine_u8", _ffi.vp(vs), _ffi.vp(vo), m, 1, fill, 1, None, st), 5), 4.306)
+if what in ("affine", "affine_fast", "all"):
+    report("rot30+1.5x bilinear fp32", timeit(lambda: _ffi.call("imgxf_affine_u8", _ffi.vp(vs), _ffi.vp(vo), m, 1, fill, 0, None, st), 5), 4.306)
+if what in ("affine", "all"):
+    m2 = _ffi.f64_array(ops.rotate_matrix(W, H, 30.0))
+    report("rot30 nearest", timeit(lambda: _ffi.call("imgxf_affine_u8", _ffi.vp(vs), _ffi.vp(vo), m2, 0, fill, 1, None, st), 5), 5.06)
+if what in ("sobel", "all"):
+    gray = torch.empty((F, H, W, 1), dtype=torch.uint8, device=dev)
+    vg = _ffi.view_of(gray)
+    report("rgb->L->sobel magnitude", timeit(lambda: _ffi.call("imgxf_rgb_sobel_mag_u8", _ffi.vp(vs), _ffi.vp(vg), st)), 4.0)
+    report("rgb2l", timeit(lambda: _ffi.call("imgxf_rgb2l_u8", _ffi.vp(vs), _ffi.vp(vg), st)), 4.0)
+if what in ("point", "all"):
+    report("brightness (blend const)", timeit(lambda: _ffi.call("imgxf_blend_u8", None, fill, _ffi.vp(vs), None, _ffi.vp(vo), 1.05, st)), 6.0)
+    report("scale_abs", timeit(lambda: _ffi.call("imgxf_scale_abs_u8", _ffi.vp(vs), _ffi.vp(vo), 0.7, 0.0, st)), 6.0)
+    report("memcpy d2d (torch copy_)", timeit(lambda: out.copy_(frames)), 6.0)
