@@ -16,7 +16,9 @@ st = torch.cuda.current_stream().cuda_stream
 vs, vo = _ffi.view_of(frames), _ffi.view_of(out)
 
 def timeit(fn, iters=10):
-    fn(); torch.cuda.synchronize()
+    for _ in range(int(os.environ.get("WARM", "1"))): fn()
+    torch.cuda.synchronize()
+    iters = int(os.environ.get("ITERS", iters))
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters): fn()
@@ -27,6 +29,8 @@ px = F * H * W
 def report(name, ms, bpp):
     print(f"{name:34s} {ms:8.3f} ms  {px/ms/1e3:10.0f} Mpix/s  {bpp*px/ms/1e6:8.1f} GB/s  {bpp*px/ms/1e6/8000*100:5.1f}% of 8 TB/s", flush=True)
 
+if what == "gauss5":
+    report("gaussian k=5", timeit(lambda: _ffi.call("imgxf_gaussian_u8", _ffi.vp(vs), _ffi.vp(vo), 5, 5/6, None, st), 20), 6.0)
 if what in ("gauss", "all"):
     for k, s in ((5, 5/6), (3, 0.5), (7, 1.0), (9, 1.5)):
         report(f"gaussian k={k}", timeit(lambda: _ffi.call("imgxf_gaussian_u8", _ffi.vp(vs), _ffi.vp(vo), k, s, None, st)), 6.0)
