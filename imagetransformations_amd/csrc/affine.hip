@@ -9,12 +9,14 @@
 #include "imgxf_common.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace imgxf {
 
 struct AffineParams {
     double m[6];
-    int fx[6];   // 16.16 fixed-point matrix for NEAREST (affine_fixed)
+    int fx[6];       // 16.16 fixed-point matrix for NEAREST (affine_fixed)
+    int64_t q0, q3;  // m0, m3 in 2^-40 fixed point (per-pixel x increments of the BILINEAR fast path)
     u8 fill[4];
 };
 
@@ -169,6 +171,232 @@ __global__ __launch_bounds__(256) void affine_kernel(View s, View d, AffineParam
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Coalesced store of a wave's output.  Every lane holds 4 consecutive pixels = 4*C bytes;
+// written straight from the lane that is C dword stores at a 4*C-byte lane stride (each
+// store instruction touches every line of the span).  Instead the wave parks its bytes in a
+// private LDS strip (conflict-free b32 writes) and reads them back as 16-byte chunks, so one
+// dwordx4 store per lane covers the span densely.  `seg_lanes` lanes form one contiguous
+// output segment (a tile row); segments need 16-byte aligned global addresses.
+// ---------------------------------------------------------------------------------------
+template <int C, int SEG_LANES>
+__device__ __forceinline__ void staged_store(u32* wlds, const u32 (&o)[C], int lane, u8* row_seg_base) {
+    // wlds: this wave's 64*C dwords.  row_seg_base: global address of the first byte of the
+    // segment (tile row) this lane belongs to — identical for all SEG_LANES lanes of a segment.
+    constexpr int SEG_BYTES = SEG_LANES * 4 * C;            // multiple of 16 (host/tile checked)
+    constexpr int CHUNKS = SEG_BYTES / 16;                  // 16-byte chunks per segment
+    constexpr int NSEG = 64 / SEG_LANES;
+#pragma unroll
+    for (int j = 0; j < C; ++j) wlds[lane * C + j] = o[j];
+    // lane t re-reads chunk (t % CHUNKS) of segment (t / CHUNKS); segment base pointers are
+    // exchanged through a second tiny LDS table (one 8-byte slot per segment)
+    u8** segtab = (u8**)(wlds + 64 * C);
+    if ((lane % SEG_LANES) == 0) segtab[lane / SEG_LANES] = row_seg_base;
+    if (lane < NSEG * CHUNKS) {
+        const int sg = lane / CHUNKS, ck = lane - sg * CHUNKS;
+        const uint4 v = *(const uint4*)(wlds + sg * (SEG_BYTES / 4) + ck * 4);
+        u8* gp = segtab[sg];
+        if (gp) *(uint4*)(gp + ck * 16) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// BILINEAR fast path (benchmark configs[3]).  Same output-stationary mapping, but
+//   - the 2x2 neighbourhood of a pixel is fetched with TWO unaligned 8-byte loads (one per
+//     source row: 2 pixels x C bytes each) instead of 4*C byte loads;
+//   - interpolation runs in fp32 FMAs on v_cvt_f32_ubyteN outputs; coordinates stay in
+//     un-contracted fp64 exactly as libImaging computes them (floor / bounds decisions and
+//     dx,dy must agree with Pillow's doubles);
+//   - PRECISE: the fp32 value is within GUARD of Pillow's fp64 value (bound derived in
+//     DESIGN.md), so (UINT8)v can only differ when the fp32 value sits within GUARD of an
+//     integer; exactly those pixels are recomputed with libImaging's fp64 sequence from the
+//     bytes already in registers.  Result: bit-identical to Pillow at close to fp32 speed.
+// Pixels whose 2x2 support touches the image border (clamped neighbours) take the generic
+// code below the fast branch.
+// ---------------------------------------------------------------------------------------
+typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+
+template <int C>
+__device__ __forceinline__ uint64_t load_pair(const u8* p) {
+    if constexpr (C == 1) return (uint64_t)(*(const u16_unaligned*)p);
+    else return *(const u64_unaligned*)p;
+}
+__device__ __forceinline__ float byte_f(uint64_t w, int i) {   // static i -> v_cvt_f32_ubyteN
+    return (float)((u32)(w >> (8 * i)) & 0xffu);
+}
+
+// Lane -> pixel mapping: a wave owns a TXG*4 x (64/TXG) pixel tile (lanes along x first),
+// a workgroup WX x (4/WX) such tiles.  A compact 2-D tile keeps the rotated source
+// footprint of one load instruction on a few cache lines (a 256x1 strip touches ~64 lines
+// per instruction at 30 degrees, a 32x8 tile ~15).  Workgroups are numbered x-fastest and
+// remapped so that each XCD (blockIdx % 8 under round-robin dispatch — speed only) walks a
+// contiguous range of tiles and re-uses its own L2 for the footprint overlap.
+template <int C, bool PRECISE, int TXG, int WX>
+__global__ __launch_bounds__(256) void affine_bilinear_kernel(View s, View d, AffineParams P, View dbg,
+                                                              int ntx, int nty, int nblocks) {
+    constexpr float GUARD = 1.0e-4f;
+    constexpr int TR = 64 / TXG, WY = 4 / WX;
+    constexpr int BW = WX * TXG * 4, BH = WY * TR;
+    // bijective XCD remap (cdna guide T1): xcd k gets a contiguous range of logical ids
+    const int orig = blockIdx.x, xcd = orig & 7, q = nblocks >> 3, r = nblocks & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int per_frame = ntx * nty;
+    const int f = logical / per_frame;
+    const int rem = logical - f * per_frame;
+    const int tyb = rem / ntx, txb = rem - tyb * ntx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = txb * BW + ((wave % WX) * TXG + (lane % TXG)) * 4;
+    const int y = tyb * BH + (wave / WX) * TR + lane / TXG;
+    // wave-uniform: the whole wave tile is inside the image and its rows start 16-B aligned
+    const int wx0 = txb * BW + (wave % WX) * TXG * 4, wy0 = tyb * BH + (wave / WX) * TR;
+    const bool staged = (TXG * 4 * C) % 16 == 0 && wx0 + TXG * 4 <= d.w && wy0 + TR <= d.h &&
+                        ((((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs | (uintptr_t)(wx0 * C)) & 15) == 0;
+    if (y >= d.h || x0 >= d.w) return;
+    const u8* sp = s.p + (int64_t)f * s.fs;
+    const double yc = (double)y + 0.5;
+    const double tx = P.m[1] * yc, ty = P.m[4] * yc;    // a1*yin, a4*yin (row constants)
+
+    // libImaging's exact fp64 evaluation of one pixel (coordinates, clamped 2x2 support, lerps):
+    // used for the lane's first pixel coordinate, and for every pixel the fast path hands back.
+    auto exact_pixel = [&](int x, u8 (&px)[C], float (&vv)[C]) {
+        const double xc = (double)x + 0.5;
+        double xin = (P.m[0] * xc + tx) + P.m[2];        // a0*xin + a1*yin + a2, un-contracted
+        double yin = (P.m[3] * xc + ty) + P.m[5];
+        if (!(xin >= 0.0 && xin < (double)s.w && yin >= 0.0 && yin < (double)s.h)) {
+#pragma unroll
+            for (int j = 0; j < C; ++j) { px[j] = P.fill[j]; vv[j] = (float)P.fill[j]; }
+            return;
+        }
+        xin -= 0.5; yin -= 0.5;
+        const double xfl = floor(xin), yfl = floor(yin);
+        const int xq = (int)xfl, yq = (int)yfl;
+        const double dxd = xin - xfl, dyd = yin - yfl;
+        const int xa = clampi(xq, 0, s.w - 1) * C, xb = clampi(xq + 1, 0, s.w - 1) * C;
+        const u8* r0 = sp + (int64_t)clampi(yq, 0, s.h - 1) * s.rs;
+        const bool has1 = (yq + 1 >= 0) && (yq + 1 < s.h);
+        const u8* r1 = sp + (int64_t)(has1 ? yq + 1 : 0) * s.rs;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const double v1 = (double)r0[xa + j] + ((double)r0[xb + j] - (double)r0[xa + j]) * dxd;
+            const double v2 = has1 ? (double)r1[xa + j] + ((double)r1[xb + j] - (double)r1[xa + j]) * dxd : v1;
+            const double v = v1 + (v2 - v1) * dyd;
+            vv[j] = (float)v; px[j] = (u8)(int)v;
+        }
+    };
+
+    // ---- phase 1: source coordinates in 2^-40 fixed point.  Pixel 0 of the lane is Pillow's
+    // own fp64 value; pixels 1..3 add k*m0 (k*m3) as 64-bit integers.  That differs from the
+    // fp64 evaluation by < 2^-37, so floor() and the bounds test can only disagree when a
+    // coordinate lies within CG = 2^-32 of an integer or half-integer: such pixels (and the
+    // ones whose 2x2 support touches the border) are handed to exact_pixel() in phase 3.
+    constexpr int64_t ONE = (int64_t)1 << 40, FMASK = ONE - 1, CG = (int64_t)1 << 8;
+    auto to_fixed = [&](double v) -> int64_t {          // |v| < 2^21 (host-checked)
+        const double fl = floor(v);
+        const double fr = (v - fl) * 256.0;              // [0, 256)
+        const double frh = floor(fr);
+        const u32 lo = (u32)((fr - frh) * 4294967296.0);
+        return ((int64_t)(int)fl << 40) + ((int64_t)(u32)(int)frh << 32) + (int64_t)lo;
+    };
+    const double xc0 = (double)x0 + 0.5;
+    const int64_t X0 = to_fixed((P.m[0] * xc0 + tx) + P.m[2]);
+    const int64_t Y0 = to_fixed((P.m[3] * xc0 + ty) + P.m[5]);
+    bool ok[4], inner[4];
+    float dxf[4], dyf[4];
+    u32 tl[4], th[4], bl[4], bh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t X = X0 + k * P.q0, Y = Y0 + k * P.q3;
+        const int xh = (int)(X >> 40), yh = (int)(Y >> 40);
+        ok[k] = xh >= 0 && xh < s.w && yh >= 0 && yh < s.h;     // 0 <= xin < w, 0 <= yin < h
+        const int64_t Xs = X - (ONE >> 1), Ys = Y - (ONE >> 1);  // xin - 0.5
+        const int xi = (int)(Xs >> 40), yi = (int)(Ys >> 40);
+        const int64_t fX = X & FMASK, fXs = Xs & FMASK, fY = Y & FMASK, fYs = Ys & FMASK;
+        const bool sure = fX >= CG && fX < ONE - CG && fXs >= CG && fXs < ONE - CG &&
+                          fY >= CG && fY < ONE - CG && fYs >= CG && fYs < ONE - CG;
+        // xin, yin far outside: the fixed-point value may have wrapped, but then it is not `ok`
+        // only if ... keep it simple: out-of-range pixels that are `sure` are final (fill)
+        inner[k] = ok[k] && sure && xi >= 0 && xi + 2 < s.w && yi >= 0 && yi + 1 < s.h;
+        if (!sure) ok[k] = true;                                // undecided: let exact_pixel decide
+        dxf[k] = (float)(u32)(fXs >> 8) * 2.3283064365386963e-10f;   // 2^-32
+        dyf[k] = (float)(u32)(fYs >> 8) * 2.3283064365386963e-10f;
+        const int64_t off = inner[k] ? (int64_t)yi * s.rs + xi * C : 0;
+        const uint64_t t = load_pair<C>(sp + off), b = load_pair<C>(sp + off + s.rs);
+        tl[k] = (u32)t; th[k] = (u32)(t >> 32); bl[k] = (u32)b; bh[k] = (u32)(b >> 32);
+    }
+    // ---- phase 2: fp32 interpolation.  |fp32 - fp64| < GUARD, so (UINT8)v is
+    // certain unless v is within GUARD of an integer; those pixels go to phase 3 when PRECISE.
+    u8 out[4 * C];
+    float vf[4][C];
+    bool redo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        redo[k] = ok[k] && !inner[k];
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            // static byte positions -> v_cvt_f32_ubyteN
+            const float a = (float)((tl[k] >> (8 * j)) & 0xffu);
+            const float b = (C + j < 4) ? (float)((tl[k] >> (8 * (C + j))) & 0xffu) : (float)((th[k] >> (8 * (C + j - 4))) & 0xffu);
+            const float c = (float)((bl[k] >> (8 * j)) & 0xffu);
+            const float e = (C + j < 4) ? (float)((bl[k] >> (8 * (C + j))) & 0xffu) : (float)((bh[k] >> (8 * (C + j - 4))) & 0xffu);
+            const float v1 = fmaf(b - a, dxf[k], a), v2 = fmaf(e - c, dxf[k], c);
+            const float v = fmaf(v2 - v1, dyf[k], v1);
+            vf[k][j] = inner[k] ? v : (float)P.fill[j];
+            out[k * C + j] = inner[k] ? (u8)(int)v : P.fill[j];
+            if (PRECISE) {
+                const float fr = v - floorf(v);
+                redo[k] |= inner[k] && (fr < GUARD || fr > 1.0f - GUARD) && !(a == b && c == e && a == c);
+            }
+        }
+    }
+    // ---- phase 3: exact fp64 evaluation of the handed-back pixels (rare)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (redo[k]) {
+            u8 px[C]; float vv[C];
+            exact_pixel(x0 + k, px, vv);
+#pragma unroll
+            for (int j = 0; j < C; ++j) { out[k * C + j] = px[j]; vf[k][j] = vv[j]; }
+        }
+    }
+    if (dbg.p) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (x0 + k < d.w) {
+                float* fp = (float*)dbg.row(f, y) + (x0 + k) * C;
+#pragma unroll
+                for (int j = 0; j < C; ++j) fp[j] = vf[k][j];
+            }
+        }
+    }
+    // ---- phase 4: store.  Full tile rows on 16-byte aligned addresses go through the LDS
+    // transpose (one dense dwordx4 store per lane); ragged right edges / unaligned views
+    // fall back to per-lane dword or byte stores.
+    u32 od[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q)
+        od[q] = (u32)out[4 * q] | ((u32)out[4 * q + 1] << 8) | ((u32)out[4 * q + 2] << 16) | ((u32)out[4 * q + 3] << 24);
+    u8* dp = d.row(f, y) + x0 * C;
+    if (staged) {
+        __shared__ __attribute__((aligned(16))) u32 stage[4][64 * C + 2 * (64 / TXG) + 4];
+        u8* seg = d.row(f, y) + (x0 - (lane % TXG) * 4) * C;
+        staged_store<C, TXG>(stage[wave], od, lane, seg);
+        return;
+    }
+    const int npx = min(4, d.w - x0);
+    if (npx == 4 && ((((uintptr_t)dp) & 3) == 0)) {
+#pragma unroll
+        for (int q = 0; q < C; ++q) ((u32*)dp)[q] = od[q];
+    } else {
+        for (int e = 0; e < npx * C; ++e) {
+            u8 v = 0;
+#pragma unroll
+            for (int kk = 0; kk < 4 * C; ++kk) if (kk == e) v = out[kk];
+            dp[e] = v;
+        }
+    }
+}
+
 static inline int fix16(double v) {
     const double t = v * 65536.0 + 0.5;
     return t < 0.0 ? (int)floor(t) : (int)t;   // libImaging FLOOR()
@@ -219,6 +447,40 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
     const View s = make_view(src), d = make_view(dst);
     hipStream_t st = (hipStream_t)stream;
     const bool pr = precise != 0 || filter == IMGXF_FILTER_NEAREST;
+    // fixed-point fast path: needs every source coordinate of the output rectangle below 2^21
+    bool fixed_ok = fabs(m[0]) < 64.0 && fabs(m[3]) < 64.0;
+    for (int cy = 0; cy < 2 && fixed_ok; ++cy)
+        for (int cx = 0; cx < 2; ++cx) {
+            const double X = (cx ? dst->w + 4 : 0) + 0.5, Y = (cy ? dst->h : 0) + 0.5;
+            const double xs = m[0] * X + m[1] * Y + m[2], ys = m[3] * X + m[4] * Y + m[5];
+            if (!(fabs(xs) < 2097152.0 && fabs(ys) < 2097152.0)) fixed_ok = false;
+        }
+    P.q0 = fixed_ok ? llround(m[0] * 1099511627776.0) : 0;
+    P.q3 = fixed_ok ? llround(m[3] * 1099511627776.0) : 0;
+    if (filter == IMGXF_FILTER_BILINEAR && (src->c == 1 || src->c == 3) && src->w >= 3 && src->h >= 2 && fixed_ok) {
+        static const int tile_env = getenv("IMGXF_AFFINE_TILE") ? atoi(getenv("IMGXF_AFFINE_TILE")) : 0;  // tuning knob
+#define IMGXF_BIL(CC, PR, TXG, WX)                                                                 \
+    do {                                                                                           \
+        constexpr int BW = WX * TXG * 4, BH = (4 / WX) * (64 / TXG);                               \
+        const int ntx = (d.w + BW - 1) / BW, nty = (d.h + BH - 1) / BH;                            \
+        const int64_t nb = (int64_t)ntx * nty * d.n;                                               \
+        if (nb > 0x7fffffff) return IMGXF_ERR_SHAPE;                                               \
+        hipLaunchKernelGGL((affine_bilinear_kernel<CC, PR, TXG, WX>), dim3((unsigned)nb), dim3(256), 0, st, \
+                           s, d, P, dbg, ntx, nty, (int)nb);                                       \
+        return launch_status();                                                                    \
+    } while (0)
+        if (src->c == 3) {
+            if (tile_env == 1) { if (pr) IMGXF_BIL(3, true, 64, 1); else IMGXF_BIL(3, false, 64, 1); }
+            if (tile_env == 2) { if (pr) IMGXF_BIL(3, true, 16, 1); else IMGXF_BIL(3, false, 16, 1); }
+            if (tile_env == 3) { if (pr) IMGXF_BIL(3, true, 8, 1); else IMGXF_BIL(3, false, 8, 1); }
+            if (tile_env == 4) { if (pr) IMGXF_BIL(3, true, 16, 2); else IMGXF_BIL(3, false, 16, 2); }
+            if (tile_env == 5) { if (pr) IMGXF_BIL(3, true, 4, 2); else IMGXF_BIL(3, false, 4, 2); }
+            if (pr) IMGXF_BIL(3, true, 8, 2); else IMGXF_BIL(3, false, 8, 2);
+        } else {
+            if (pr) IMGXF_BIL(1, true, 8, 2); else IMGXF_BIL(1, false, 8, 2);
+        }
+#undef IMGXF_BIL
+    }
     switch (src->c) {
         case 1: return pr ? launch_affine_filter<1, PreciseArith>(filter, s, d, P, dbg, st)
                           : launch_affine_filter<1, FastArith>(filter, s, d, P, dbg, st);
