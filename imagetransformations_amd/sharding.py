@@ -1,0 +1,104 @@
+"""Frame sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+The hot path has no cross-frame dependency (the reference's outer loop over images,
+/root/reference/transformation.py:113, is embarrassingly parallel), so a batch shards by
+FRAME in contiguous blocks and the compute needs no collective at all.  The only exchange
+steps are the optional scatter of a root-resident batch to the ranks and the gather of the
+results: point-to-point sends from/to the root (RCCL send/recv — one direct xGMI link per
+peer), batched so all 7 links of the root run concurrently.  Works with the `nccl` (= RCCL)
+backend on device tensors and with `gloo` on host tensors (used by the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_counts(n_frames: int, world: int) -> list[int]:
+    """Contiguous block sizes; the first n % world ranks take one extra frame."""
+    if n_frames < 0 or world < 1:
+        raise ValueError("n_frames >= 0 and world >= 1 required")
+    base, extra = divmod(n_frames, world)
+    return [base + (1 if r < extra else 0) for r in range(world)]
+
+
+def shard_range(n_frames: int, world: int, rank: int) -> tuple[int, int]:
+    """[start, stop) of the frames owned by `rank`."""
+    counts = shard_counts(n_frames, world)
+    start = sum(counts[:rank])
+    return start, start + counts[rank]
+
+
+def _world(group=None) -> tuple[int, int]:
+    if not dist.is_available() or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def scatter_frames(frames: Optional[torch.Tensor], n_frames: int, frame_shape: Sequence[int],
+                   device: torch.device, root: int = 0, group=None) -> torch.Tensor:
+    """Root holds `frames` [n_frames, *frame_shape] uint8; every rank returns its block."""
+    rank, world = _world(group)
+    start, stop = shard_range(n_frames, world, rank)
+    if world == 1:
+        return frames[start:stop]
+    local = torch.empty((stop - start, *frame_shape), dtype=torch.uint8, device=device)
+    ops = []
+    if rank == root:
+        for peer in range(world):
+            s, e = shard_range(n_frames, world, peer)
+            if peer == root:
+                local.copy_(frames[s:e])
+            elif e > s:
+                ops.append(dist.P2POp(dist.isend, frames[s:e].contiguous(), peer, group))
+    elif stop > start:
+        ops.append(dist.P2POp(dist.irecv, local, root, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return local
+
+
+def gather_frames(local: torch.Tensor, n_frames: int, root: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Inverse of scatter_frames: the root returns [n_frames, ...], other ranks None."""
+    rank, world = _world(group)
+    if world == 1:
+        return local
+    out = None
+    ops = []
+    if rank == root:
+        out = torch.empty((n_frames, *local.shape[1:]), dtype=local.dtype, device=local.device)
+        for peer in range(world):
+            s, e = shard_range(n_frames, world, peer)
+            if peer == root:
+                out[s:e].copy_(local)
+            elif e > s:
+                ops.append(dist.P2POp(dist.irecv, out[s:e], peer, group))
+    elif local.shape[0] > 0:
+        ops.append(dist.P2POp(dist.isend, local.contiguous(), root, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
+
+
+def map_frames(fn: Callable[[torch.Tensor], torch.Tensor], frames: Optional[torch.Tensor], n_frames: int,
+               frame_shape: Sequence[int], device: torch.device, root: int = 0, group=None):
+    """scatter -> fn(local block) -> gather.  `fn` is any per-batch op from `ops` (or a
+    composition); it runs on each rank's block with no communication."""
+    local = scatter_frames(frames, n_frames, frame_shape, device, root, group)
+    out = fn(local) if local.shape[0] > 0 else local
+    return gather_frames(out, n_frames, root, group)
+
+
+def checksum(t: torch.Tensor, group=None) -> int:
+    """Order-independent checksum of a sharded batch: sum over ranks of sum(bytes * position
+    weight).  Equal for any sharding of the same frames when `offset` numbering is global."""
+    rank, world = _world(group)
+    v = t.reshape(t.shape[0], -1).to(torch.int64).sum(dim=1) if t.shape[0] else torch.zeros(0, dtype=torch.int64, device=t.device)
+    total = v.sum().reshape(1)
+    if world > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return int(total.item())

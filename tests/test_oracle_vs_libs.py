@@ -1,0 +1,88 @@
+"""CPU: pin the NumPy oracle against the installed Pillow / SciPy / NumPy — the third-party
+kernels the reference calls — using the reference's argument lists (file:line cited in
+oracle/imgxf_oracle.py).  Skipped where those libraries are not importable."""
+import numpy as np
+import pytest
+
+from conftest import synth
+from oracle import imgxf_oracle as O
+
+Image = pytest.importorskip("PIL.Image")
+ImageEnhance = pytest.importorskip("PIL.ImageEnhance")
+ndimage = pytest.importorskip("scipy.ndimage")
+
+SIZES = [(32, 32), (37, 61), (334, 500)]
+
+
+@pytest.mark.parametrize("hw", SIZES)
+def test_rotation_family(hw):
+    a = synth(1, *hw)
+    img = Image.fromarray(a)
+    w, h = img.size
+    for ang in O.grid_values("rotation") + [30.0, 45.0, 90.0, 180.0, 270.0, 359.0]:
+        assert np.array_equal(O.apply_rotation(a, ang), np.asarray(img.rotate(-ang, fillcolor=(0, 0, 0), expand=False))), ang
+    for ang in (30.0, -22.5, 7.0):
+        assert np.array_equal(O.rotate_bilinear(a, ang),
+                              np.asarray(img.rotate(ang, resample=Image.BILINEAR, fillcolor=(0, 0, 0))))
+    m = O.rotate_zoom_matrix(w, h, 30.0, 1.5)
+    for flt, fn in ((Image.NEAREST, O.affine_nearest), (Image.BILINEAR, O.affine_bilinear), (Image.BICUBIC, O.affine_bicubic)):
+        ref = img.transform((w, h), Image.AFFINE, m, resample=flt, fillcolor=(3, 2, 1))
+        assert np.array_equal(fn(a, (w, h), m, fill=(3, 2, 1)), np.asarray(ref))
+    for mm in ((1, 0, 3.3, 0, 1, -2.7), (0.7, 0, -3, 0, 1.3, 5), (1.5, 0, 10.2, 0, 0.5, 0.3)):
+        ref = img.transform((w + 5, h - 3), Image.AFFINE, mm, resample=Image.NEAREST, fillcolor=(9, 8, 7))
+        assert np.array_equal(O.affine_nearest(a, (w + 5, h - 3), [float(v) for v in mm], fill=(9, 8, 7)), np.asarray(ref))
+
+
+@pytest.mark.parametrize("hw", SIZES)
+def test_scale_shear_translation(hw):
+    a = synth(2, *hw)
+    img = Image.fromarray(a)
+    w, h = img.size
+    for s in O.grid_values("scale") + [1.5, 0.5, 2.75 / 3.0]:
+        nw, nh = int(w * s), int(h * s)
+        assert np.array_equal(O.resize_lanczos(a, (nw, nh)), np.asarray(img.resize((nw, nh), Image.Resampling.LANCZOS))), s
+    for sh in O.grid_values("shear"):
+        nw, m = O.shear_geometry(w, h, sh)
+        ref = img.transform((nw, h), Image.AFFINE, m, resample=Image.BICUBIC, fillcolor=(255, 255, 255))
+        assert np.array_equal(O.apply_shear(a, sh), np.asarray(ref)), sh
+
+
+@pytest.mark.parametrize("hw", SIZES)
+def test_colour_and_mask_ops(hw):
+    a = synth(3, *hw)
+    img = Image.fromarray(a)
+    for b in O.grid_values("lighten_darken") + [0.5, -0.5, 1.0]:
+        assert np.array_equal(O.apply_brightness(a, b), np.asarray(ImageEnhance.Brightness(img).enhance(1.0 + b))), b
+    g = O.rgb2l(a)
+    assert np.array_equal(g, np.asarray(img.convert('L')))
+    assert np.array_equal(O.sobel_scipy(g), ndimage.sobel(g))
+    assert np.array_equal(O.sobel_scipy(g, 0), ndimage.sobel(g, 0))
+    e = ndimage.sobel(g)
+    for q in (70, 50, 1, 99, 33.3, 0, 100):
+        assert O.percentile_linear_u8(e, q) == float(np.percentile(e, q)), q
+    msk = e > np.percentile(e, 70)
+    assert np.array_equal(O.binary_dilation_cross(msk, 3), ndimage.binary_dilation(msk, iterations=3))
+    bg = Image.new('RGB', img.size, (51, 127, 229))
+    assert np.array_equal(O.apply_background_change_simple(a, (0.2, 0.5, 0.9)), np.asarray(Image.blend(img, bg, 0.3)))
+    b2 = synth(4, *hw)
+    for alpha in (0.0, 0.25, 1.0, 1.5, -0.5):
+        assert np.array_equal(O.blend(a, b2, alpha), np.asarray(Image.blend(img, Image.fromarray(b2), alpha))), alpha
+
+
+def test_c_oracle_matches_numpy_oracle():
+    """The plain-C restatement (cpu_baseline leg of bench.py) equals the NumPy oracle."""
+    from oracle import c_oracle as CO
+    CO.set_threads(2)
+    for hw in ((37, 61), (135, 240)):
+        a = synth(5, *hw)
+        h, w = hw
+        for k, s in ((5, 5 / 6), (3, 0.5), (31, 5.0)):
+            assert np.array_equal(CO.gaussian_blur(a, k, s), O.gaussian_blur(a, k, s))
+        m = O.rotate_zoom_matrix(w, h, 30.0, 1.5)
+        assert np.array_equal(CO.affine(a, (w, h), m, 1, (0, 0, 0)), O.affine_bilinear(a, (w, h), m, (0, 0, 0)))
+        m2 = O.rotate_plan(w, h, -22.5)[1]
+        assert np.array_equal(CO.affine(a, (w, h), m2, 0, (0, 0, 0)), O.affine_nearest(a, (w, h), m2, (0, 0, 0)))
+        g = O.rgb2l(a)
+        assert np.array_equal(CO.rgb2l(a), g)
+        assert np.array_equal(CO.sobel(g, 0), O.sobel_scipy(g, -1))
+        assert np.array_equal(CO.sobel(g, 2), O.sobel_magnitude(g))
