@@ -1,0 +1,34 @@
+"""`TransformationPool` members that sit on the hot path, with the
+reference's static-method style and argument meaning
+(/root/reference/pipenline/cifar_image_transformations.py:37-129).  The remaining members
+(Pillow GaussianBlur box approximation, ImageEnhance.Contrast/Color/Sharpness, histogram
+equalisation, impulse / shot noise) are SURVEY §8f "next" rows and are not provided yet:
+asking for them raises AttributeError rather than silently running on the CPU."""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+from PIL import Image
+
+from . import ops
+from .transformation import _download, _upload
+
+
+class TransformationPool:
+    def motion_blur(image, size=None):
+        """cifar_image_transformations.py:109-119: cv2.filter2D with a horizontal 1/size row."""
+        if size is None:
+            size = random.choice([5, 7, 9, 11])
+        kernel = np.zeros((size, size))
+        kernel[int((size - 1) / 2), :] = np.ones(size)
+        kernel = kernel / size
+        return _download(ops.conv2d(_upload(image), kernel.tolist()))
+
+    def enhance_brightness(image, factor=None):
+        """cifar_image_transformations.py:89-93: ImageEnhance.Brightness(image).enhance(factor)."""
+        if factor is None:
+            factor = random.uniform(0.5, 2.0)
+        if image.mode not in ("RGB", "L"):
+            raise NotImplementedError(f"enhance_brightness supports RGB and L images, got {image.mode!r}")
+        return _download(ops.brightness(_upload(image), factor))
