@@ -17,6 +17,8 @@ struct AffineParams {
     double m[6];
     int fx[6];       // 16.16 fixed-point matrix for NEAREST (affine_fixed)
     int64_t q0, q3;  // m0, m3 in 2^-40 fixed point (per-pixel x increments of the BILINEAR fast path)
+    int64_t q1, q4;  // m1, m4 likewise (per-row increments, LDS-staged path)
+    int64_t x00, y00; // xin-.5, yin-.5 of output pixel (0,0) in 2^-40 fixed point (Pillow's fp64 value)
     u8 fill[4];
 };
 
@@ -216,6 +218,7 @@ __device__ __forceinline__ void staged_store(u32* wlds, const u32 (&o)[C], int l
 // ---------------------------------------------------------------------------------------
 typedef uint64_t u64_unaligned __attribute__((aligned(1)));
 typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
 template <int C>
 __device__ __forceinline__ uint64_t load_pair(const u8* p) {
@@ -397,6 +400,211 @@ __global__ __launch_bounds__(256) void affine_bilinear_kernel(View s, View d, Af
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// BILINEAR, LDS-staged source tile (RGB).  The three gather kernels above all cost ~79 cycles
+// per 64-lane load instruction on the texture-address path (PMC: every lane that touches a
+// different cache line is serialised), independent of their VALU work.  Here a workgroup
+// (64x16 output pixels) first copies the bounding box of its rotated source footprint from
+// global memory into LDS with coalesced row-wise loads (lanes walk consecutive pixels of a
+// source row), expanded to one dword per pixel (RGBX), and then gathers its 2x2 supports
+// from LDS with one ds_read2_b32 per source row.  Coordinates, guard logic and the exact
+// fp64 hand-back are the same as in affine_bilinear_kernel.
+// ---------------------------------------------------------------------------------------
+template <bool PRECISE, int PITCH>
+__global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d, AffineParams P, View dbg,
+                                                                  int ntx, int nty) {
+    constexpr int C = 3, TXG = 8, WX = 2, TR = 8, BW = 64, BH = 16;
+    constexpr float GUARD = 1.2e-4f;
+    constexpr int FONE = 1 << 24, FHALF = 1 << 23, CG32 = 1 << 6;   // 8.24 tile-relative coordinates
+    extern __shared__ __attribute__((aligned(16))) u32 srct[];      // bbox pixels, RGBX, row pitch PITCH
+    __shared__ __attribute__((aligned(16))) u32 stage[4][64 * C + 2 * (64 / TXG) + 4];
+
+    // tiles of one frame are numbered x-fastest and remapped so each XCD walks a contiguous range
+    const int nblocks = ntx * nty;
+    const int orig = blockIdx.x, xcd = orig & 7, q = nblocks >> 3, r = nblocks & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int f = blockIdx.y;
+    const int tyb = logical / ntx, txb = logical - tyb * ntx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx = ((wave % WX) * TXG + (lane % TXG)) * 4, ly = (wave / WX) * TR + lane / TXG;
+    const int x0 = txb * BW + lx, y = tyb * BH + ly;
+    const int wx0 = txb * BW + (wave % WX) * TXG * 4, wy0 = tyb * BH + (wave / WX) * TR;
+    const bool staged = wx0 + TXG * 4 <= d.w && wy0 + TR <= d.h &&
+                        ((((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs | (uintptr_t)(wx0 * C)) & 15) == 0;
+    const bool valid = y < d.h && x0 < d.w;
+    const u8* sp = s.p + (int64_t)f * s.fs;
+
+    // ---- tile-origin source coordinate (xin-.5, yin-.5) in 2^-40 fixed point: the host converts
+    // Pillow's fp64 value for output pixel (0,0) once; tiles add integer multiples of the matrix
+    // (scalar 64-bit arithmetic, error < 2^-27 px over a 32k image, far inside the 2^-18 guard)
+    const int64_t XT = P.x00 + (int64_t)(txb * BW) * P.q0 + (int64_t)(tyb * BH) * P.q1;
+    const int64_t YT = P.y00 + (int64_t)(txb * BW) * P.q3 + (int64_t)(tyb * BH) * P.q4;
+    // bounding box of floor(xin-.5) .. +1 over the tile: the map is affine, extremes are corners
+    const int64_t ax = (BW - 1) * P.q0, bx = (BH - 1) * P.q1, ay = (BW - 1) * P.q3, by = (BH - 1) * P.q4;
+    const int64_t xlo = XT + min(ax, (int64_t)0) + min(bx, (int64_t)0), xhi = XT + max(ax, (int64_t)0) + max(bx, (int64_t)0);
+    const int64_t ylo = YT + min(ay, (int64_t)0) + min(by, (int64_t)0), yhi = YT + max(ay, (int64_t)0) + max(by, (int64_t)0);
+    const int ux_lo = (int)(xlo >> 40), uy_lo = (int)(ylo >> 40);              // unclipped origin
+    const int sx_lo = max(ux_lo, 0), sx_hi = min((int)(xhi >> 40) + 1, s.w - 1);
+    const int sy_lo = max(uy_lo, 0), sy_hi = min((int)(yhi >> 40) + 1, s.h - 1);
+    const int bwc = sx_hi - sx_lo + 1, bhc = sy_hi - sy_lo + 1;    // <= 0: tile sees no source pixel
+
+    // ---- stage the bounding box: wave w copies rows w, w+4, ...; lanes walk consecutive pixels
+    // of a source row (unaligned 4-byte loads at a 3-byte lane stride: two cache lines per
+    // instruction).  The frame's very last pixel cannot be read with a 4-byte load, so the one
+    // tile that owns it reads that pixel from 1 byte earlier and shifts.
+    const bool owns_last = sy_hi == s.h - 1 && sx_hi == s.w - 1;           // block-uniform
+    for (int cc = lane; cc < bwc; cc += 64) {
+        const u8* gp = sp + (int64_t)(sy_lo + wave) * s.rs + (sx_lo + cc) * 3;
+        u32* lp = srct + wave * PITCH + cc;
+        const int64_t gstep = 4 * s.rs;
+        if (!owns_last) {
+#pragma unroll 4
+            for (int rr = wave; rr < bhc; rr += 4) {
+                *lp = *(const u32_unaligned*)gp;
+                gp += gstep;
+                lp += 4 * PITCH;
+            }
+        } else {
+            const u8* frame_last4 = sp + (int64_t)(s.h - 1) * s.rs + (int64_t)s.w * 3 - 4;
+            for (int rr = wave; rr < bhc; rr += 4) {
+                const bool tail = gp > frame_last4;
+                const u32 v = *(const u32_unaligned*)(tail ? gp - 1 : gp);
+                *lp = tail ? v >> 8 : v;
+                gp += gstep;
+                lp += 4 * PITCH;
+            }
+        }
+    }
+    __syncthreads();
+
+    auto exact_pixel = [&](int x, u8 (&px)[C], float (&vv)[C]) {
+        const double xc = (double)x + 0.5, yc = (double)y + 0.5;
+        double xin = (P.m[0] * xc + P.m[1] * yc) + P.m[2];
+        double yin = (P.m[3] * xc + P.m[4] * yc) + P.m[5];
+        if (!(xin >= 0.0 && xin < (double)s.w && yin >= 0.0 && yin < (double)s.h)) {
+#pragma unroll
+            for (int j = 0; j < C; ++j) { px[j] = P.fill[j]; vv[j] = (float)P.fill[j]; }
+            return;
+        }
+        xin -= 0.5; yin -= 0.5;
+        const double xfl = floor(xin), yfl = floor(yin);
+        const int xq = (int)xfl, yq = (int)yfl;
+        const double dxd = xin - xfl, dyd = yin - yfl;
+        const int xa = clampi(xq, 0, s.w - 1) * C, xb = clampi(xq + 1, 0, s.w - 1) * C;
+        const u8* r0 = sp + (int64_t)clampi(yq, 0, s.h - 1) * s.rs;
+        const bool has1 = (yq + 1 >= 0) && (yq + 1 < s.h);
+        const u8* r1 = sp + (int64_t)(has1 ? yq + 1 : 0) * s.rs;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const double v1 = (double)r0[xa + j] + ((double)r0[xb + j] - (double)r0[xa + j]) * dxd;
+            const double v2 = has1 ? (double)r1[xa + j] + ((double)r1[xb + j] - (double)r1[xa + j]) * dxd : v1;
+            const double v = v1 + (v2 - v1) * dyd;
+            vv[j] = (float)v; px[j] = (u8)(int)v;
+        }
+    };
+
+    // ---- per-pixel coordinates: 64-bit adds, then 8.24 fixed point relative to the UNCLIPPED
+    // bbox origin (|rel| < 128 px, host-checked).  The integer part indexes the LDS tile, the
+    // fraction is dx / dy.  A coordinate within 2^-18 of an integer or half-integer (where the
+    // truncation to 24 fraction bits could change floor() or the bounds test) hands the pixel
+    // to exact_pixel(); so does a 2x2 support that touches the image border.
+    const int64_t XL = XT + lx * P.q0 + ly * P.q1 - ((int64_t)ux_lo << 40);
+    const int64_t YL = YT + lx * P.q3 + ly * P.q4 - ((int64_t)uy_lo << 40);
+    const int offx = ux_lo - sx_lo, offy = uy_lo - sy_lo;          // <= 0 where the bbox was clipped
+    u8 out[4 * C];
+    float vf[4][C];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int X32 = (int)((XL + k * P.q0) >> 16), Y32 = (int)((YL + k * P.q3) >> 16);
+        const int xi = (X32 >> 24) + offx, yi = (Y32 >> 24) + offy;          // relative to the clipped bbox
+        const u32 fx = (u32)X32 & (FONE - 1), fy = (u32)Y32 & (FONE - 1);
+        const bool sure = ((fx & (FHALF - 1)) - CG32) < (u32)(FHALF - 2 * CG32) &&
+                          ((fy & (FHALF - 1)) - CG32) < (u32)(FHALF - 2 * CG32);
+        const bool inner = valid && sure && bwc > 1 && bhc > 1 && (u32)xi < (u32)(bwc - 1) && (u32)yi < (u32)(bhc - 1);
+        const float dxf = (float)fx * 5.9604644775390625e-08f;               // 2^-24
+        const float dyf = (float)fy * 5.9604644775390625e-08f;
+        const int li = inner ? yi * PITCH + xi : 0;
+        const u32 p00 = srct[li], p01 = srct[li + 1], p10 = srct[li + PITCH], p11 = srct[li + PITCH + 1];
+        bool near_int = false;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const float a = (float)((p00 >> (8 * j)) & 0xffu), b = (float)((p01 >> (8 * j)) & 0xffu);
+            const float c = (float)((p10 >> (8 * j)) & 0xffu), e = (float)((p11 >> (8 * j)) & 0xffu);
+            const float v1 = fmaf(b - a, dxf, a), v2 = fmaf(e - c, dxf, c);
+            const float v = fmaf(v2 - v1, dyf, v1);
+            const float fl = floorf(v);                                      // v >= 0: (UINT8)v == floor(v)
+            vf[k][j] = inner ? v : (float)P.fill[j];
+            out[k * C + j] = inner ? (u8)(int)fl : P.fill[j];
+            if (PRECISE) near_int |= fabsf((v - fl) - 0.5f) > 0.5f - GUARD;
+        }
+        if (inner) {
+            if (PRECISE) {
+                // a flat 2x2 support is exact in both arithmetics: not worth the fp64 redo
+                const bool flat = (((p00 ^ p01) | (p10 ^ p11) | (p00 ^ p10)) << 8) == 0;
+                if (near_int && !flat) {
+                    // the support is certain (`sure`): only dx, dy and the lerps need libImaging's
+                    // fp64 sequence, on the taps already in registers
+                    const double xc = (double)(x0 + k) + 0.5, yc = (double)y + 0.5;
+                    const double xin = ((P.m[0] * xc + P.m[1] * yc) + P.m[2]) - 0.5;
+                    const double yin = ((P.m[3] * xc + P.m[4] * yc) + P.m[5]) - 0.5;
+                    const double dxd = xin - floor(xin), dyd = yin - floor(yin);
+#pragma unroll
+                    for (int j = 0; j < C; ++j) {
+                        const double a = (double)((p00 >> (8 * j)) & 0xffu), b = (double)((p01 >> (8 * j)) & 0xffu);
+                        const double c = (double)((p10 >> (8 * j)) & 0xffu), e = (double)((p11 >> (8 * j)) & 0xffu);
+                        const double v1 = a + (b - a) * dxd, v2 = c + (e - c) * dxd;
+                        const double v = v1 + (v2 - v1) * dyd;
+                        vf[k][j] = (float)v; out[k * C + j] = (u8)(int)v;
+                    }
+                }
+            }
+        } else if (valid && x0 + k < d.w) {
+            // far outside the image: plain fill; anything else that is not `inner` goes to fp64
+            const int xa = xi + sx_lo, ya = yi + sy_lo;
+            const bool far_out = sure && (xa < -1 || xa > s.w || ya < -1 || ya > s.h);
+            if (!far_out) {
+                u8 px[C]; float vv[C];
+                exact_pixel(x0 + k, px, vv);
+#pragma unroll
+                for (int j = 0; j < C; ++j) { out[k * C + j] = px[j]; vf[k][j] = vv[j]; }
+            }
+        }
+    }
+    if (dbg.p && valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (x0 + k < d.w) {
+                float* fp = (float*)dbg.row(f, y) + (x0 + k) * C;
+#pragma unroll
+                for (int j = 0; j < C; ++j) fp[j] = vf[k][j];
+            }
+        }
+    }
+    u32 od[C];
+#pragma unroll
+    for (int qq = 0; qq < C; ++qq)
+        od[qq] = (u32)out[4 * qq] | ((u32)out[4 * qq + 1] << 8) | ((u32)out[4 * qq + 2] << 16) | ((u32)out[4 * qq + 3] << 24);
+    if (staged) {
+        u8* seg = d.row(f, y) + (x0 - (lane % TXG) * 4) * C;
+        staged_store<C, TXG>(stage[wave], od, lane, seg);
+        return;
+    }
+    if (!valid) return;
+    u8* dp = d.row(f, y) + x0 * C;
+    const int npx = min(4, d.w - x0);
+    if (npx == 4 && ((((uintptr_t)dp) & 3) == 0)) {
+#pragma unroll
+        for (int qq = 0; qq < C; ++qq) ((u32*)dp)[qq] = od[qq];
+    } else {
+        for (int e = 0; e < npx * C; ++e) {
+            u8 v = 0;
+#pragma unroll
+            for (int kk = 0; kk < 4 * C; ++kk) if (kk == e) v = out[kk];
+            dp[e] = v;
+        }
+    }
+}
+
 static inline int fix16(double v) {
     const double t = v * 65536.0 + 0.5;
     return t < 0.0 ? (int)floor(t) : (int)t;   // libImaging FLOOR()
@@ -457,8 +665,38 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
         }
     P.q0 = fixed_ok ? llround(m[0] * 1099511627776.0) : 0;
     P.q3 = fixed_ok ? llround(m[3] * 1099511627776.0) : 0;
+    fixed_ok = fixed_ok && fabs(m[1]) < 64.0 && fabs(m[4]) < 64.0;
+    P.q1 = fixed_ok ? llround(m[1] * 1099511627776.0) : 0;
+    P.q4 = fixed_ok ? llround(m[4] * 1099511627776.0) : 0;
+    if (fixed_ok) {
+        const double x0d = (m[0] * 0.5 + m[1] * 0.5) + m[2] - 0.5, y0d = (m[3] * 0.5 + m[4] * 0.5) + m[5] - 0.5;
+        P.x00 = (int64_t)floor(x0d * 1099511627776.0);
+        P.y00 = (int64_t)floor(y0d * 1099511627776.0);
+    }
     if (filter == IMGXF_FILTER_BILINEAR && (src->c == 1 || src->c == 3) && src->w >= 3 && src->h >= 2 && fixed_ok) {
         static const int tile_env = getenv("IMGXF_AFFINE_TILE") ? atoi(getenv("IMGXF_AFFINE_TILE")) : 0;  // tuning knob
+        static const bool no_lds = getenv("IMGXF_AFFINE_NO_LDS") != nullptr;
+        if (src->c == 3 && !no_lds && tile_env == 0 &&
+            ((((uintptr_t)src->data) | (uintptr_t)src->row_stride | (uintptr_t)src->frame_stride) & 3) == 0) {
+            // source bounding box of a 64x16 output tile (translation-invariant up to rounding)
+            const int bw = (int)ceil(fabs(m[0]) * 63 + fabs(m[1]) * 15) + 4;
+            const int bh = (int)ceil(fabs(m[3]) * 63 + fabs(m[4]) * 15) + 4;
+            const int ntx = (d.w + 63) / 64, nty = (d.h + 15) / 16;
+            if (bw <= 97 && bh <= 100 && (int64_t)ntx * nty < 0x7fffffff && d.n <= 65535) {
+                dim3 grid((unsigned)(ntx * nty), (unsigned)d.n);
+#define IMGXF_LDS(PITCH)                                                                           \
+    do {                                                                                           \
+        const size_t lds = (size_t)PITCH * bh * 4 + 16;                                            \
+        if (pr) hipLaunchKernelGGL((affine_bilinear_lds_kernel<true, PITCH>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty); \
+        else hipLaunchKernelGGL((affine_bilinear_lds_kernel<false, PITCH>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty);  \
+        return launch_status();                                                                    \
+    } while (0)
+                if (bw <= 49) IMGXF_LDS(49);
+                if (bw <= 65) IMGXF_LDS(65);
+                IMGXF_LDS(97);
+#undef IMGXF_LDS
+            }
+        }
 #define IMGXF_BIL(CC, PR, TXG, WX)                                                                 \
     do {                                                                                           \
         constexpr int BW = WX * TXG * 4, BH = (4 / WX) * (64 / TXG);                               \
@@ -471,10 +709,6 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
     } while (0)
         if (src->c == 3) {
             if (tile_env == 1) { if (pr) IMGXF_BIL(3, true, 64, 1); else IMGXF_BIL(3, false, 64, 1); }
-            if (tile_env == 2) { if (pr) IMGXF_BIL(3, true, 16, 1); else IMGXF_BIL(3, false, 16, 1); }
-            if (tile_env == 3) { if (pr) IMGXF_BIL(3, true, 8, 1); else IMGXF_BIL(3, false, 8, 1); }
-            if (tile_env == 4) { if (pr) IMGXF_BIL(3, true, 16, 2); else IMGXF_BIL(3, false, 16, 2); }
-            if (tile_env == 5) { if (pr) IMGXF_BIL(3, true, 4, 2); else IMGXF_BIL(3, false, 4, 2); }
             if (pr) IMGXF_BIL(3, true, 8, 2); else IMGXF_BIL(3, false, 8, 2);
         } else {
             if (pr) IMGXF_BIL(1, true, 8, 2); else IMGXF_BIL(1, false, 8, 2);

@@ -1,0 +1,60 @@
+// VALU issue-rate probe for gfx950 (development aid): cycles per wave64 instruction per SIMD
+// for the instruction kinds the image kernels are made of.  8 independent chains per lane,
+// 8 waves per SIMD, every CU busy; rate = total wave-instructions / (SIMDs * clock * time).
+// build: hipcc -O3 --offload-arch=gfx950 tools/exp_valu.hip -o /tmp/exp_valu
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#define N_ITER 4096
+#define CHAINS 8
+template <int KIND>
+__global__ __launch_bounds__(256) void k(float* out, float seed) {
+    float a[CHAINS]; uint32_t u[CHAINS]; double dd[CHAINS]; uint64_t q[CHAINS];
+#pragma unroll
+    for (int i = 0; i < CHAINS; ++i) { a[i] = seed + i + threadIdx.x; u[i] = (uint32_t)(threadIdx.x * 2654435761u + i); dd[i] = a[i]; q[i] = u[i]; }
+    for (int it = 0; it < N_ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < CHAINS; ++i) {
+            if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(seed));
+            if (KIND == 1) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a[i]) : "v"(u[i]));
+            if (KIND == 2) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 3) asm volatile("v_add_f64 %0, %0, %1" : "+v"(dd[i]) : "v"(dd[(i + 1) % CHAINS]));
+            if (KIND == 4) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(dd[i]) : "v"(dd[(i + 1) % CHAINS]));
+            if (KIND == 5) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q[i]) : "v"(q[(i + 1) % CHAINS]));
+            if (KIND == 6) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(dd[i]) : "v"(dd[(i + 1) % CHAINS]));
+            if (KIND == 7) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(u[i]) : "v"(a[i]));
+            if (KIND == 8) asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 9) asm volatile("v_floor_f64 %0, %1" : "=v"(dd[i]) : "v"(dd[(i + 1) % CHAINS]));
+            if (KIND == 10) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(u[i]) : "v"(dd[i]));
+            if (KIND == 11) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[i]) : "v"(u[i]), "v"(u[(i + 1) % CHAINS]) : "vcc");
+            if (KIND == 12) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]) : "vcc");
+            if (KIND == 13) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(dd[i]) : "v"(dd[(i + 1) % CHAINS]));
+            if (KIND == 14) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(u[i]), "v"(u[(i + 1) % CHAINS]) : "vcc");
+            if (KIND == 15) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < CHAINS; ++i) s += a[i] + (float)u[i] + (float)dd[i] + (float)q[i];
+    if (s == 12345.678f) out[0] = s;
+}
+template <int KIND> void run(const char* name) {
+    float* out; hipMalloc(&out, 4);
+    const int blocks = 256 * 8;   // 8 blocks of 4 waves per CU = 8 waves per SIMD
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 1.0f);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 1.0f);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double winstr = (double)blocks * 4 * N_ITER * CHAINS;      // wave-instructions
+    const double per_simd = winstr / 1024.0;
+    printf("%-20s %8.3f ms  -> %6.2f cycles per wave64 instruction per SIMD at 2.4 GHz\n", name, ms, ms * 1e-3 * 2.4e9 / per_simd);
+}
+int main() {
+    run<0>("v_fma_f32"); run<1>("v_cvt_f32_ubyte1"); run<2>("v_add_u32"); run<12>("v_cndmask_b32"); run<14>("v_cmp_lt_u32");
+    run<8>("v_alignbit_b32"); run<7>("v_cvt_pk_u8_f32"); run<15>("v_mov_b32_dpp wave_shr");
+    run<6>("v_pk_fma_f32"); run<3>("v_add_f64"); run<13>("v_mul_f64"); run<4>("v_fma_f64"); run<9>("v_floor_f64"); run<10>("v_cvt_i32_f64");
+    run<5>("v_lshl_add_u64"); run<11>("v_mad_u64_u32");
+    return 0;
+}
