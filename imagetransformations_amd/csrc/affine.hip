@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void affine_bilinear_kernel(View s, View d, Af
 // BILINEAR, LDS-staged source tile (RGB).  The three gather kernels above all cost ~79 cycles
 // per 64-lane load instruction on the texture-address path (PMC: every lane that touches a
 // different cache line is serialised), independent of their VALU work.  Here a workgroup
-// (64x16 output pixels) first copies the bounding box of its rotated source footprint from
+// (32x32 output pixels) first copies the bounding box of its rotated source footprint from
 // global memory into LDS with coalesced row-wise loads (lanes walk consecutive pixels of a
 // source row), expanded to one dword per pixel (RGBX), and then gathers its 2x2 supports
 // from LDS with one ds_read2_b32 per source row.  Coordinates, guard logic and the exact
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void affine_bilinear_kernel(View s, View d, Af
 template <bool PRECISE, int PITCH>
 __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d, AffineParams P, View dbg,
                                                                   int ntx, int nty) {
-    constexpr int C = 3, TXG = 8, WX = 2, TR = 8, BW = 64, BH = 16;
+    constexpr int C = 3, TXG = 8, WX = 1, TR = 8, BW = 32, BH = 32;   // square tile: smallest rotated bbox
     constexpr float GUARD = 1.2e-4f;
     constexpr int FONE = 1 << 24, FHALF = 1 << 23, CG32 = 1 << 6;   // 8.24 tile-relative coordinates
     extern __shared__ __attribute__((aligned(16))) u32 srct[];      // bbox pixels, RGBX, row pitch PITCH
@@ -605,6 +605,91 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// NEAREST (Image.rotate, /root/reference/transformation.py:200), LDS-staged like the bilinear
+// kernel: libImaging's affine_fixed integers (16.16, C-int wrap) give the source pixel of
+// every output pixel exactly, so there is no guard and no fp64 at all — stage the bounding
+// box of the tile's source pixels, read one RGBX dword per output pixel from LDS.
+// ---------------------------------------------------------------------------------------
+template <int PITCH>
+__global__ __launch_bounds__(256) void affine_nearest_lds_kernel(View s, View d, AffineParams P, int ntx, int nty) {
+    constexpr int C = 3, TXG = 8, WX = 1, TR = 8, BW = 32, BH = 32;   // square tile: smallest rotated bbox
+    extern __shared__ __attribute__((aligned(16))) u32 srct[];
+    __shared__ __attribute__((aligned(16))) u32 stage[4][64 * C + 2 * (64 / TXG) + 4];
+    const int nblocks = ntx * nty;
+    const int orig = blockIdx.x, xcd = orig & 7, q = nblocks >> 3, r = nblocks & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int f = blockIdx.y;
+    const int tyb = logical / ntx, txb = logical - tyb * ntx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx = ((wave % WX) * TXG + (lane % TXG)) * 4, ly = (wave / WX) * TR + lane / TXG;
+    const int x0 = txb * BW + lx, y = tyb * BH + ly;
+    const int wx0 = txb * BW + (wave % WX) * TXG * 4, wy0 = tyb * BH + (wave / WX) * TR;
+    const bool staged = wx0 + TXG * 4 <= d.w && wy0 + TR <= d.h &&
+                        ((((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs | (uintptr_t)(wx0 * C)) & 15) == 0;
+    const bool valid = y < d.h && x0 < d.w;
+    const u8* sp = s.p + (int64_t)f * s.fs;
+
+    // source coordinate of the tile origin and its extremes over the tile (host guarantees no
+    // 32-bit wrap inside the output rectangle, so plain int arithmetic equals libImaging's)
+    const int XT = P.fx[2] + P.fx[1] * (tyb * BH) + P.fx[0] * (txb * BW);
+    const int YT = P.fx[5] + P.fx[4] * (tyb * BH) + P.fx[3] * (txb * BW);
+    const int ax = (BW - 1) * P.fx[0], bx = (BH - 1) * P.fx[1], ay = (BW - 1) * P.fx[3], by = (BH - 1) * P.fx[4];
+    const int sx_lo = max((XT + min(ax, 0) + min(bx, 0)) >> 16, 0), sx_hi = min((XT + max(ax, 0) + max(bx, 0)) >> 16, s.w - 1);
+    const int sy_lo = max((YT + min(ay, 0) + min(by, 0)) >> 16, 0), sy_hi = min((YT + max(ay, 0) + max(by, 0)) >> 16, s.h - 1);
+    const int bwc = sx_hi - sx_lo + 1, bhc = sy_hi - sy_lo + 1;
+
+    const bool owns_last = sy_hi == s.h - 1 && sx_hi == s.w - 1;
+    for (int cc = lane; cc < bwc; cc += 64) {
+        const u8* gp = sp + (int64_t)(sy_lo + wave) * s.rs + (sx_lo + cc) * 3;
+        u32* lp = srct + wave * PITCH + cc;
+        const int64_t gstep = 4 * s.rs;
+        if (!owns_last) {
+#pragma unroll 4
+            for (int rr = wave; rr < bhc; rr += 4) { *lp = *(const u32_unaligned*)gp; gp += gstep; lp += 4 * PITCH; }
+        } else {
+            const u8* frame_last4 = sp + (int64_t)(s.h - 1) * s.rs + (int64_t)s.w * 3 - 4;
+            for (int rr = wave; rr < bhc; rr += 4) {
+                const bool tail = gp > frame_last4;
+                const u32 v = *(const u32_unaligned*)(tail ? gp - 1 : gp);
+                *lp = tail ? v >> 8 : v;
+                gp += gstep; lp += 4 * PITCH;
+            }
+        }
+    }
+    __syncthreads();
+
+    const u32 fillw = (u32)P.fill[0] | ((u32)P.fill[1] << 8) | ((u32)P.fill[2] << 16);
+    const int XL = XT + lx * P.fx[0] + ly * P.fx[1], YL = YT + lx * P.fx[3] + ly * P.fx[4];
+    u32 px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xi = ((XL + k * P.fx[0]) >> 16) - sx_lo, yi = ((YL + k * P.fx[3]) >> 16) - sy_lo;
+        const bool in = bwc > 0 && bhc > 0 && (u32)xi < (u32)bwc && (u32)yi < (u32)bhc;
+        const u32 v = srct[in ? yi * PITCH + xi : 0];
+        px[k] = in ? (v & 0xffffffu) : fillw;
+    }
+    // 4 RGBX pixels -> 12 packed bytes
+    u32 od[3];
+    od[0] = px[0] | (px[1] << 24);
+    od[1] = (px[1] >> 8) | (px[2] << 16);
+    od[2] = (px[2] >> 16) | (px[3] << 8);
+    if (staged) {
+        u8* seg = d.row(f, y) + (x0 - (lane % TXG) * 4) * C;
+        staged_store<C, TXG>(stage[wave], od, lane, seg);
+        return;
+    }
+    if (!valid) return;
+    u8* dp = d.row(f, y) + x0 * C;
+    const int npx = min(4, d.w - x0);
+    if (npx == 4 && ((((uintptr_t)dp) & 3) == 0)) {
+#pragma unroll
+        for (int qq = 0; qq < C; ++qq) ((u32*)dp)[qq] = od[qq];
+    } else {
+        for (int e = 0; e < npx * C; ++e) dp[e] = (u8)(px[e / 3] >> (8 * (e % 3)));
+    }
+}
+
 static inline int fix16(double v) {
     const double t = v * 65536.0 + 0.5;
     return t < 0.0 ? (int)floor(t) : (int)t;   // libImaging FLOOR()
@@ -655,6 +740,28 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
     const View s = make_view(src), d = make_view(dst);
     hipStream_t st = (hipStream_t)stream;
     const bool pr = precise != 0 || filter == IMGXF_FILTER_NEAREST;
+    if (filter == IMGXF_FILTER_NEAREST && src->c == 3 && getenv("IMGXF_AFFINE_NO_LDS") == nullptr &&
+        ((((uintptr_t)src->data) | (uintptr_t)src->row_stride | (uintptr_t)src->frame_stride) & 3) == 0) {
+        // 16.16 coordinates must not wrap 32 bits anywhere in the (tile-padded) output rectangle
+        bool nowrap = true;
+        for (int cy = 0; cy < 2; ++cy)
+            for (int cx = 0; cx < 2; ++cx) {
+                const double X = cx ? dst->w + 32 : 0, Y = cy ? dst->h + 32 : 0;
+                const double xs = (double)P.fx[2] + (double)P.fx[1] * Y + (double)P.fx[0] * X;
+                const double ys = (double)P.fx[5] + (double)P.fx[4] * Y + (double)P.fx[3] * X;
+                if (fabs(xs) > 2.0e9 || fabs(ys) > 2.0e9) nowrap = false;
+            }
+        const int bw = (int)ceil((fabs((double)P.fx[0]) * 31 + fabs((double)P.fx[1]) * 31) / 65536.0) + 3;
+        const int bh = (int)ceil((fabs((double)P.fx[3]) * 31 + fabs((double)P.fx[4]) * 31) / 65536.0) + 3;
+        const int ntx = (d.w + 31) / 32, nty = (d.h + 31) / 32;
+        if (nowrap && bw <= 97 && bh <= 100 && (int64_t)ntx * nty < 0x7fffffff && d.n <= 65535) {
+            dim3 grid((unsigned)(ntx * nty), (unsigned)d.n);
+            if (bw <= 49) hipLaunchKernelGGL((affine_nearest_lds_kernel<49>), grid, dim3(256), (size_t)49 * bh * 4 + 16, st, s, d, P, ntx, nty);
+            else if (bw <= 65) hipLaunchKernelGGL((affine_nearest_lds_kernel<65>), grid, dim3(256), (size_t)65 * bh * 4 + 16, st, s, d, P, ntx, nty);
+            else hipLaunchKernelGGL((affine_nearest_lds_kernel<97>), grid, dim3(256), (size_t)97 * bh * 4 + 16, st, s, d, P, ntx, nty);
+            return launch_status();
+        }
+    }
     // fixed-point fast path: needs every source coordinate of the output rectangle below 2^21
     bool fixed_ok = fabs(m[0]) < 64.0 && fabs(m[3]) < 64.0;
     for (int cy = 0; cy < 2 && fixed_ok; ++cy)
@@ -678,10 +785,10 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
         static const bool no_lds = getenv("IMGXF_AFFINE_NO_LDS") != nullptr;
         if (src->c == 3 && !no_lds && tile_env == 0 &&
             ((((uintptr_t)src->data) | (uintptr_t)src->row_stride | (uintptr_t)src->frame_stride) & 3) == 0) {
-            // source bounding box of a 64x16 output tile (translation-invariant up to rounding)
-            const int bw = (int)ceil(fabs(m[0]) * 63 + fabs(m[1]) * 15) + 4;
-            const int bh = (int)ceil(fabs(m[3]) * 63 + fabs(m[4]) * 15) + 4;
-            const int ntx = (d.w + 63) / 64, nty = (d.h + 15) / 16;
+            // source bounding box of a 32x32 output tile (translation-invariant up to rounding)
+            const int bw = (int)ceil(fabs(m[0]) * 31 + fabs(m[1]) * 31) + 4;
+            const int bh = (int)ceil(fabs(m[3]) * 31 + fabs(m[4]) * 31) + 4;
+            const int ntx = (d.w + 31) / 32, nty = (d.h + 31) / 32;
             if (bw <= 97 && bh <= 100 && (int64_t)ntx * nty < 0x7fffffff && d.n <= 65535) {
                 dim3 grid((unsigned)(ntx * nty), (unsigned)d.n);
 #define IMGXF_LDS(PITCH)                                                                           \
