@@ -12,87 +12,107 @@
 
 namespace imgxf {
 
-struct Color4 { u8 v[4]; };
-
-// A "row job" is one image row of one frame; rows are independent byte runs.
-// Each workgroup walks rows; inside a row lanes take 16-byte chunks.
-template <class Op>
+// A lane owns one chunk of a row: 16 bytes, or 48 bytes (= 16 RGB pixels) when C == 3 so that
+// the channel of every byte position is a compile-time constant (per-channel constants then
+// cost nothing).  Full, 16-byte aligned chunks move as uint4; ragged row ends and unaligned
+// views go byte by byte.  Ops return fp32 that v_cvt_pk_u8_f32 packs (round-half-even,
+// saturating); ops with truncating semantics floor() first.
+template <int C, class Op>
 __global__ __launch_bounds__(256) void map_rows_kernel(View a, View b, View d, Op op) {
-    const int rowbytes = d.w * d.c;
-    const int nchunks = (rowbytes + 15) >> 4;
+    constexpr int NV = (C == 3) ? 3 : 1, CB = 16 * NV;
+    const int rowbytes = d.w * C;
+    const int nchunks = (rowbytes + CB - 1) / CB;
     const int64_t total = (int64_t)d.n * d.h * nchunks;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int ck = (int)(t % nchunks);
         const int64_t r = t / nchunks;
         const int y = (int)(r % d.h), f = (int)(r / d.h);
-        const int xb = ck << 4;
+        const int xb = ck * CB;
         const u8* ap = a.p ? a.row(f, y) + xb : nullptr;
         const u8* bp = b.p ? b.row(f, y) + xb : nullptr;
         u8* dp = d.row(f, y) + xb;
-        const int nv = min(16, rowbytes - xb);
-        u32 av[4] = {0, 0, 0, 0}, bv[4] = {0, 0, 0, 0}, ov[4];
-        const bool vec = nv == 16 && (((uintptr_t)dp | (uintptr_t)ap | (uintptr_t)bp) & 15) == 0;
+        const int nv = min(CB, rowbytes - xb);
+        u32 av[4 * NV], bv[4 * NV], ov[4 * NV];
+        const bool vec = nv == CB && (((uintptr_t)dp | (uintptr_t)ap | (uintptr_t)bp) & 15) == 0;
         if (vec) {
-            if (ap) { const uint4 q = *(const uint4*)ap; av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w; }
-            if (bp) { const uint4 q = *(const uint4*)bp; bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w; }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (ap) { const uint4 q = ((const uint4*)ap)[k]; av[4 * k] = q.x; av[4 * k + 1] = q.y; av[4 * k + 2] = q.z; av[4 * k + 3] = q.w; }
+                if (bp) { const uint4 q = ((const uint4*)bp)[k]; bv[4 * k] = q.x; bv[4 * k + 1] = q.y; bv[4 * k + 2] = q.z; bv[4 * k + 3] = q.w; }
+            }
         } else {
+#pragma unroll
+            for (int k = 0; k < 4 * NV; ++k) { av[k] = 0; bv[k] = 0; }
             for (int e = 0; e < nv; ++e) {
-                if (ap) av[e >> 2] |= (u32)ap[e] << (8 * (e & 3));
-                if (bp) bv[e >> 2] |= (u32)bp[e] << (8 * (e & 3));
+                const u32 x = ap ? ap[e] : 0, z = bp ? bp[e] : 0;
+#pragma unroll
+                for (int k = 0; k < 4 * NV; ++k)
+                    if ((e >> 2) == k) { av[k] |= x << (8 * (e & 3)); bv[k] |= z << (8 * (e & 3)); }
             }
         }
-        int ch = xb % d.c;
+        if (!ap) { for (int k = 0; k < 4 * NV; ++k) av[k] = 0; }
+        if (!bp) { for (int k = 0; k < 4 * NV; ++k) bv[k] = 0; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4 * NV; ++k) {
             u32 o = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const u32 pa = (av[k] >> (8 * e)) & 0xffu, pb = (bv[k] >> (8 * e)) & 0xffu;
-                o |= (op(pa, pb, ch) & 0xffu) << (8 * e);
-                ch = (ch + 1 == d.c) ? 0 : ch + 1;
+                const float pa = (float)((av[k] >> (8 * e)) & 0xffu), pb = (float)((bv[k] >> (8 * e)) & 0xffu);
+                o = __builtin_amdgcn_cvt_pk_u8_f32(op(pa, pb, (4 * k + e) % C), e, o);
             }
             ov[k] = o;
         }
         if (vec) {
-            *(uint4*)dp = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) ((uint4*)dp)[k] = make_uint4(ov[4 * k], ov[4 * k + 1], ov[4 * k + 2], ov[4 * k + 3]);
         } else {
-            for (int e = 0; e < nv; ++e) dp[e] = (u8)(ov[e >> 2] >> (8 * (e & 3)));
+            for (int e = 0; e < nv; ++e) {
+                u32 w = 0;
+#pragma unroll
+                for (int k = 0; k < 4 * NV; ++k) if ((e >> 2) == k) w = ov[k];
+                dp[e] = (u8)(w >> (8 * (e & 3)));
+            }
         }
     }
 }
 
-__device__ __forceinline__ u32 pick(const Color4& c, int ch) {
-    return ch == 0 ? c.v[0] : ch == 1 ? c.v[1] : ch == 2 ? c.v[2] : c.v[3];
-}
+struct Color4f { float v[4]; };
 
-// libImaging Blend.c: float32 in1 + alpha*(in2-in1)
+// libImaging Blend.c: float32 in1 + alpha*(in2-in1), truncated ((UINT8) cast); outside
+// 0 <= alpha <= 1 the value is clipped to [0,255] first.  floor() + the saturating pack
+// reproduce both: in range the value is >= 0 so floor == truncation, out of range the pack
+// saturates exactly where Blend.c clips (<= 0 -> 0, >= 255 -> 255).
 struct BlendOp {
-    float alpha; int clip; int const1, const2; Color4 c1, c2;
-    __device__ __forceinline__ u32 operator()(u32 pa, u32 pb, int ch) const {
-        const int i1 = const1 ? (int)pick(c1, ch) : (int)pa;
-        const int i2 = const2 ? (int)pick(c2, ch) : (int)pb;
-        const float t = __fadd_rn((float)i1, __fmul_rn(alpha, (float)(i2 - i1)));
-        if (!clip) return (u32)(int)t;
-        return t <= 0.0f ? 0u : (t >= 255.0f ? 255u : (u32)(int)t);
+    float alpha; int const1, const2; Color4f c1, c2;
+    __device__ __forceinline__ float operator()(float pa, float pb, int ch) const {
+        const float i1 = const1 ? c1.v[ch] : pa;
+        const float i2 = const2 ? c2.v[ch] : pb;
+        const float t = i1 + alpha * (i2 - i1);      // un-contracted (library-wide -ffp-contract=off)
+        return floorf(t);
     }
 };
 
 // cv2.convertScaleAbs: saturate_cast<uchar>(|alpha*p + beta|)
 struct ScaleAbsOp {
     float alpha, beta;
-    __device__ __forceinline__ u32 operator()(u32 pa, u32, int) const {
-        const float v = fabsf(__fadd_rn(__fmul_rn((float)pa, alpha), beta));
-        return sat_u8_rne(v);
+    __device__ __forceinline__ float operator()(float pa, float, int) const {
+        return fabsf(pa * alpha + beta);
     }
 };
 
 template <class Op>
 static int launch_map(const View& a, const View& b, const View& d, const Op& op, hipStream_t st) {
-    const int64_t total = (int64_t)d.n * d.h * ((d.rowbytes() + 15) >> 4);
+    const int cb = d.c == 3 ? 48 : 16;
+    const int64_t total = (int64_t)d.n * d.h * ((d.rowbytes() + cb - 1) / cb);
     if (total == 0) return IMGXF_OK;
     int64_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL((map_rows_kernel<Op>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, d, op);
+    if (blocks > 16384) blocks = 16384;
+    switch (d.c) {
+        case 1: hipLaunchKernelGGL((map_rows_kernel<1, Op>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, d, op); break;
+        case 2: hipLaunchKernelGGL((map_rows_kernel<2, Op>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, d, op); break;
+        case 3: hipLaunchKernelGGL((map_rows_kernel<3, Op>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, d, op); break;
+        default: hipLaunchKernelGGL((map_rows_kernel<4, Op>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, d, op); break;
+    }
     return launch_status();
 }
 
@@ -255,14 +275,13 @@ IMGXF_API int imgxf_blend_u8(const imgxf_view* im1, const uint8_t* color1, const
     View a, b; memset(&a, 0, sizeof(a)); memset(&b, 0, sizeof(b));
     BlendOp op; memset(&op, 0, sizeof(op));
     op.alpha = alpha;
-    op.clip = !(alpha >= 0.0f && alpha <= 1.0f);
     if (im1) {
         IMGXF_CHECK(check_view(im1));
         if (!same_geometry(im1, dst)) return IMGXF_ERR_SHAPE;
         a = make_view(im1);
     } else {
         op.const1 = 1;
-        for (int j = 0; j < dst->c; ++j) op.c1.v[j] = color1[j];
+        for (int j = 0; j < dst->c; ++j) op.c1.v[j] = (float)color1[j];
     }
     if (im2) {
         IMGXF_CHECK(check_view(im2));
@@ -270,7 +289,7 @@ IMGXF_API int imgxf_blend_u8(const imgxf_view* im1, const uint8_t* color1, const
         b = make_view(im2);
     } else {
         op.const2 = 1;
-        for (int j = 0; j < dst->c; ++j) op.c2.v[j] = color2[j];
+        for (int j = 0; j < dst->c; ++j) op.c2.v[j] = (float)color2[j];
     }
     return launch_map(a, b, make_view(dst), op, (hipStream_t)stream);
 }
