@@ -6,8 +6,9 @@
 // resolved while loading) into LDS as fp32, each lane then owns one byte column x 8 rows.
 // sobel:  LDS-staged L tile (the RGB->L conversion is fused into the tile load for the
 // benchmark variant), exact int32 gradients.
-#include "imgxf_common.h"
+#include "sobel_march.inc"
 #include <string.h>
+#include <stdlib.h>
 
 namespace imgxf {
 
@@ -126,6 +127,14 @@ IMGXF_API int imgxf_sobel_u8(const imgxf_view* src, const imgxf_view* dst, int v
     if (variant < 0 || variant > 2) return IMGXF_ERR_ARG;
     if (empty_view(src)) return IMGXF_OK;
     const View s = make_view(src), d = make_view(dst);
+    static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
+    if (!no_march && sobel_march_eligible(s, d, 1)) {
+        switch (variant) {
+            case IMGXF_SOBEL_X_WRAP: return launch_sobel_march<1, IMGXF_SOBEL_X_WRAP>(s, d, (hipStream_t)stream);
+            case IMGXF_SOBEL_Y_WRAP: return launch_sobel_march<1, IMGXF_SOBEL_Y_WRAP>(s, d, (hipStream_t)stream);
+            default: return launch_sobel_march<1, IMGXF_SOBEL_MAGNITUDE>(s, d, (hipStream_t)stream);
+        }
+    }
     dim3 grid((unsigned)((s.w + 63) / 64), (unsigned)((s.h + 15) / 16), (unsigned)s.n);
     hipLaunchKernelGGL((sobel_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, s, d, variant);
     return launch_status();
@@ -137,6 +146,9 @@ IMGXF_API int imgxf_rgb_sobel_mag_u8(const imgxf_view* src, const imgxf_view* ds
     if (!same_nhw(src, dst) || src->c != 3 || dst->c != 1) return IMGXF_ERR_SHAPE;
     if (empty_view(src)) return IMGXF_OK;
     const View s = make_view(src), d = make_view(dst);
+    static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
+    if (!no_march && sobel_march_eligible(s, d, 3))
+        return launch_sobel_march<3, IMGXF_SOBEL_MAGNITUDE>(s, d, (hipStream_t)stream);
     dim3 grid((unsigned)((s.w + 63) / 64), (unsigned)((s.h + 15) / 16), (unsigned)s.n);
     hipLaunchKernelGGL((sobel_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, s, d,
                        (int)IMGXF_SOBEL_MAGNITUDE);

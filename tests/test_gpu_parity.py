@@ -306,3 +306,30 @@ def test_full_size_4k_properties(device):
     m = O.rotate_zoom_matrix(3840, 2160, 30.0, 1.5)
     got = host(ops.affine(t, m, (3840, 2160), ops.BILINEAR, (0, 0, 0), precise=True))
     assert np.array_equal(got, O.affine_bilinear(a, (3840, 2160), m, fill=(0, 0, 0)))
+
+
+@pytest.mark.parametrize("hw", [(40, 1040), (33, 2048), (64, 1056), (1080, 1920)])
+def test_sobel_marching_path_bit_exact(device, hw):
+    """Widths > 1024 and multiples of 16 take the LDS-DMA marching kernel: strips of 1024
+    pixels incl. a 1-lane last strip (1040), exact strip multiples (2048) and 1080p."""
+    from imagetransformations_amd import ops, _ffi
+    a = synth(41, *hw)
+    g = O.rgb2l(a)
+    t = dev(g, device)
+    assert np.array_equal(host(ops.sobel(t, _ffi.SOBEL_X_WRAP)), O.sobel_scipy(g, -1))
+    assert np.array_equal(host(ops.sobel(t, _ffi.SOBEL_Y_WRAP)), O.sobel_scipy(g, 0))
+    assert np.array_equal(host(ops.sobel(t, _ffi.SOBEL_MAGNITUDE)), O.sobel_magnitude(g))
+    assert np.array_equal(host(ops.rgb_sobel_magnitude(dev(a, device))), O.sobel_magnitude(g))
+    batch = np.stack([a, synth(42, *hw)])
+    out = host(ops.rgb_sobel_magnitude(dev(batch, device)))
+    assert np.array_equal(out[1, ..., 0], O.rgb_sobel_magnitude(batch[1]))
+
+
+@pytest.mark.parametrize("hw", [(40, 1040), (70, 2048), (1080, 1920)])
+@pytest.mark.parametrize("k", [3, 5, 7, 9])
+def test_gaussian_marching_path_edge_geometries(device, hw, k):
+    from imagetransformations_amd import ops
+    a = synth(43, *hw)
+    sigma = {3: 0.5, 5: 5 / 6, 7: 1.0, 9: 1.5}[k]
+    out, f32 = ops.gaussian_blur(dev(a, device), k, sigma, return_f32=True)
+    assert_quantised_close(host(out), host(f32), O.gaussian_blur_f64(a, k, sigma), O.saturate_u8)
