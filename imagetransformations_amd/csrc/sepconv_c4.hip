@@ -1,7 +1,7 @@
 // sepconv kernels for C=4 interleaved channels: register-marching fast path
 // (sepconv_march.inc) when rows are 16-byte aligned and the halo fits one block,
 // LDS-tiled general path (sepconv_tile.inc) otherwise.
-#include "sepconv_march.inc"
+#include "sepconv_march4.inc"
 #include <stdlib.h>
 namespace imgxf {
 int sepconv_c4(int R, const View& s, const View& d, const View& df, const Taps& taps,
@@ -13,6 +13,14 @@ int sepconv_c4(int R, const View& s, const View& d, const View& df, const Taps& 
 #define IMGXF_M(r) case r: return launch_sepconv_march<4, r>(s, d, df, taps, st, rpw_env);
             IMGXF_M(1) IMGXF_M(2) IMGXF_M(3)
 #undef IMGXF_M
+            default: break;
+        }
+    }
+    if (!no_march && march4_eligible(s, d, df, 4, R, border)) {
+        switch (R) {
+#define IMGXF_M4(r) case r: return launch_sepconv_march4<4, r>(s, d, df, taps, st);
+            IMGXF_M4(4) IMGXF_M4(5) IMGXF_M4(6) IMGXF_M4(7) IMGXF_M4(8) IMGXF_M4(9) IMGXF_M4(10) IMGXF_M4(11) IMGXF_M4(12) IMGXF_M4(13) IMGXF_M4(14) IMGXF_M4(15)
+#undef IMGXF_M4
             default: break;
         }
     }

@@ -333,3 +333,23 @@ def test_gaussian_marching_path_edge_geometries(device, hw, k):
     sigma = {3: 0.5, 5: 5 / 6, 7: 1.0, 9: 1.5}[k]
     out, f32 = ops.gaussian_blur(dev(a, device), k, sigma, return_f32=True)
     assert_quantised_close(host(out), host(f32), O.gaussian_blur_f64(a, k, sigma), O.saturate_u8)
+
+
+@pytest.mark.parametrize("hw", [(64, 352), (70, 1040), (45, 2048), (540, 960)])
+@pytest.mark.parametrize("radius", [2.0, 2.5, 3.5, 5.0])
+def test_gaussian_large_radius_marching_path(device, hw, radius):
+    """k = 13 .. 31 on 16-byte aligned rows: the narrow (4 bytes per lane) marching kernel,
+    incl. a single short last strip (352*3 = 1056 B) and image-border reflection in it."""
+    from imagetransformations_amd import ops
+    a = synth(44, *hw)
+    k = O.blur_ksize(radius)
+    out, f32 = ops.gaussian_blur(dev(a, device), k, radius, return_f32=True)
+    assert_quantised_close(host(out), host(f32), O.gaussian_blur_f64(a, k, radius), O.saturate_u8)
+
+
+def test_gaussian_large_radius_gray_and_rgba(device):
+    from imagetransformations_amd import ops
+    for c, w in ((1, 1024), (4, 320)):
+        a = synth(45, 50, w, c)
+        out, f32 = ops.gaussian_blur(dev(a, device), 25, 4.0, return_f32=True)
+        assert_quantised_close(host(out), host(f32), O.gaussian_blur_f64(a, 25, 4.0), O.saturate_u8)
