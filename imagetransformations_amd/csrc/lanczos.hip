@@ -6,6 +6,7 @@
 #include <math.h>
 #include <string.h>
 #include <vector>
+#include <stdlib.h>
 
 #define PRECISION_BITS (32 - 8 - 2)
 
@@ -16,11 +17,20 @@ struct imgxf_lanczos_plan {
     int* d_kk_x;             // [out_w][ksx]
     int* d_bounds_y;         // [out_h][2]
     int* d_kk_y;             // [out_h][ksy]
+    // window-normalised copies for the fast kernels: every window is KP samples wide and lies
+    // fully inside the source (start = min(xmin, in - KP)), coefficients shifted accordingly
+    int kpx, kpy;            // padded window widths (kpx in {8,12,16}; 0 = fast kernel not usable)
+    int* d_start_x;          // [out_w]
+    int* d_pk_x;             // [out_w][kpx]
+    int* d_start_y;          // [out_h]
+    int* d_pk_y;             // [out_h][kpy]
     uint8_t* d_tmp;          // [max_frames][in_h][out_w][c], only when both passes run
     int need_h, need_v;
 };
 
 namespace imgxf {
+
+typedef uint32_t u32_ua __attribute__((aligned(1)));
 
 static inline double sinc_filter(double x) {
     if (x == 0.0) return 1.0;
@@ -68,8 +78,26 @@ static int build_coeffs(int in_size, int out_size, std::vector<int>& bounds, std
     return ksize;
 }
 
+// window-normalised tables: start[i] = min(xmin, in_size - KP); pk[i][start-relative] = coeff
+static void build_padded(int in_size, int out_size, int ksize, int KP, const std::vector<int>& bounds,
+                         const std::vector<int>& kk, std::vector<int>& start, std::vector<int>& pk) {
+    start.assign(out_size, 0);
+    pk.assign((size_t)out_size * KP, 0);
+    for (int i = 0; i < out_size; ++i) {
+        const int xmin = bounds[2 * i], cnt = bounds[2 * i + 1];
+        int st = xmin;
+        if (st > in_size - KP) st = in_size - KP;
+        start[i] = st;
+        for (int x = 0; x < cnt; ++x) pk[(size_t)i * KP + (xmin - st) + x] = kk[(size_t)i * ksize + x];
+    }
+}
+
 __device__ __forceinline__ u8 clip8(int v) {
     v >>= PRECISION_BITS;
+    // keep the shift and the clamp apart: hipcc (ROCm 7.2) otherwise fuses pairs of them into
+    // v_ashr_pk_u8_i32 and ORs further bytes into its result as if bits 31:16 were zero, which
+    // they are not on gfx950 (observed: every third byte of a packed dword corrupted)
+    asm volatile("" : "+v"(v));
     return (u8)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
@@ -117,9 +145,124 @@ __global__ __launch_bounds__(256) void resample_v_kernel(View s, View d, const i
     }
 }
 
+// ---- fast horizontal pass (RGB): a lane owns 4 adjacent output columns, keeps their 4 x KP
+// coefficients in registers and marches down ROWS_PER_BLOCK rows; each column's window is
+// KP*3 bytes = KP*3/4 unaligned dword loads that start exactly at the window's first pixel
+// (no shifting), every byte feeds one v_mad_i32_i24.  Windows never leave the row (tables are
+// start-clamped on the host) and KP*3 is a multiple of 4, so no load passes the row end.
+template <int KP>
+__global__ __launch_bounds__(256) void resample_h_fast_kernel(View s, View d, const int* start, const int* pk,
+                                                              int rows_per_block) {
+    constexpr int C = 3, ND = KP * 3 / 4;
+    const int xg = blockIdx.x * 256 + threadIdx.x;          // group of 4 output columns
+    const int x0 = xg * 4;
+    const int f = blockIdx.z;
+    const int y_begin = blockIdx.y * rows_per_block, y_end = min(d.h, y_begin + rows_per_block);
+    if (x0 >= d.w) return;
+    int st[4];
+    int kc[4][KP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xx = min(x0 + j, d.w - 1);
+        st[j] = start[xx] * C;
+#pragma unroll
+        for (int t = 0; t < KP; ++t) kc[j][t] = pk[(int64_t)xx * KP + t];
+    }
+    const int npx = min(4, d.w - x0);
+    for (int y = y_begin; y < y_end; ++y) {
+        const u8* rowp = s.row(f, y);
+        u32 out[4 * C];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32 w[ND];
+            const u8* wp = rowp + st[j];
+#pragma unroll
+            for (int q = 0; q < ND; ++q) w[q] = *(const u32_ua*)(wp + 4 * q);
+            int acc[C];
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) acc[ch] = 1 << (PRECISION_BITS - 1);
+#pragma unroll
+            for (int t = 0; t < KP; ++t) {
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    const int b = t * C + ch;
+                    acc[ch] += (int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu) * kc[j][t];
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) out[j * C + ch] = clip8(acc[ch]);
+        }
+        u8* dp = d.row(f, y) + x0 * C;
+        if (npx == 4 && (((uintptr_t)dp) & 3) == 0) {
+#pragma unroll
+            for (int q = 0; q < C; ++q)
+                ((u32*)dp)[q] = out[4 * q] | (out[4 * q + 1] << 8) | (out[4 * q + 2] << 16) | (out[4 * q + 3] << 24);
+        } else {
+            for (int e = 0; e < npx * C; ++e) {
+                u32 v = 0;
+#pragma unroll
+                for (int k = 0; k < 4 * C; ++k) if (k == e) v = out[k];
+                dp[e] = (u8)v;
+            }
+        }
+    }
+}
+
+// ---- fast vertical pass: a lane owns 16 bytes of an output row; the KP window rows are read
+// with coalesced 16-byte loads, the coefficient of a row is wave-uniform (scalar load), rows
+// with a zero coefficient are skipped.
+__global__ __launch_bounds__(256) void resample_v_fast_kernel(View s, View d, const int* start, const int* pk, int KP) {
+    const int rowbytes = d.w * d.c;                         // multiple of 16 (host-checked)
+    const int nchunks = rowbytes >> 4;
+    const int ck = blockIdx.x * 256 + threadIdx.x;
+    const int yy = blockIdx.y, f = blockIdx.z;
+    if (ck >= nchunks) return;
+    const int y0 = start[yy];
+    const int* k = pk + (int64_t)yy * KP;
+    int acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 1 << (PRECISION_BITS - 1);
+    const u8* sp = s.row(f, y0) + (ck << 4);
+    for (int t = 0; t < KP; ++t) {
+        const int c = k[t];
+        if (c != 0) {
+            const uint4 q = *(const uint4*)(sp + (int64_t)t * s.rs);
+            const u32 w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += (int)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) * c;
+        }
+    }
+    u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e >> 2] |= (u32)clip8(acc[e]) << (8 * (e & 3));
+    *(uint4*)(d.row(f, yy) + (ck << 4)) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 static inline unsigned grid_for(int64_t total) {
     int64_t blocks = (total + 255) / 256;
     return (unsigned)(blocks > 16384 ? 16384 : (blocks < 1 ? 1 : blocks));
+}
+
+static int launch_h_fast(const imgxf_lanczos_plan* p, const View& s, const View& d, hipStream_t st) {
+    const int rpb = 32;
+    dim3 grid((unsigned)((d.w + 1023) / 1024), (unsigned)((d.h + rpb - 1) / rpb), (unsigned)d.n);
+    switch (p->kpx) {
+        case 8: hipLaunchKernelGGL((resample_h_fast_kernel<8>), grid, dim3(256), 0, st, s, d, p->d_start_x, p->d_pk_x, rpb); break;
+        case 12: hipLaunchKernelGGL((resample_h_fast_kernel<12>), grid, dim3(256), 0, st, s, d, p->d_start_x, p->d_pk_x, rpb); break;
+        default: hipLaunchKernelGGL((resample_h_fast_kernel<16>), grid, dim3(256), 0, st, s, d, p->d_start_x, p->d_pk_x, rpb); break;
+    }
+    return launch_status();
+}
+
+static bool v_fast_ok(const imgxf_lanczos_plan* p, const View& s, const View& d) {
+    return p->kpy > 0 && (d.rowbytes() % 16) == 0 &&
+           ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | ((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs) & 15) == 0;
+}
+
+static int launch_v_fast(const imgxf_lanczos_plan* p, const View& s, const View& d, hipStream_t st) {
+    dim3 grid((unsigned)(((d.rowbytes() >> 4) + 255) / 256), (unsigned)d.h, (unsigned)d.n);
+    hipLaunchKernelGGL(resample_v_fast_kernel, grid, dim3(256), 0, st, s, d, p->d_start_y, p->d_pk_y, p->kpy);
+    return launch_status();
 }
 
 static int launch_h(const View& s, const View& d, const int* b, const int* k, int ks, hipStream_t st) {
@@ -161,11 +304,25 @@ IMGXF_API int imgxf_lanczos_plan_create(imgxf_lanczos_plan** plan, int in_h, int
         std::vector<int> b, k;
         p->ksx = build_coeffs(in_w, out_w, b, k);
         if ((rc = upload(b, &p->d_bounds_x)) == IMGXF_OK) rc = upload(k, &p->d_kk_x);
+        const int kp = p->ksx <= 8 ? 8 : (p->ksx <= 12 ? 12 : (p->ksx <= 16 ? 16 : 0));
+        if (rc == IMGXF_OK && c == 3 && kp && in_w >= kp) {
+            std::vector<int> st, pk;
+            build_padded(in_w, out_w, p->ksx, kp, b, k, st, pk);
+            p->kpx = kp;
+            if ((rc = upload(st, &p->d_start_x)) == IMGXF_OK) rc = upload(pk, &p->d_pk_x);
+        }
     }
     if (rc == IMGXF_OK && p->need_v) {
         std::vector<int> b, k;
         p->ksy = build_coeffs(in_h, out_h, b, k);
         if ((rc = upload(b, &p->d_bounds_y)) == IMGXF_OK) rc = upload(k, &p->d_kk_y);
+        const int kp = p->ksy;
+        if (rc == IMGXF_OK && in_h >= kp) {
+            std::vector<int> st, pk;
+            build_padded(in_h, out_h, p->ksy, kp, b, k, st, pk);
+            p->kpy = kp;
+            if ((rc = upload(st, &p->d_start_y)) == IMGXF_OK) rc = upload(pk, &p->d_pk_y);
+        }
     }
     if (rc == IMGXF_OK && p->need_h && p->need_v) {
         hipError_t e = hipMalloc((void**)&p->d_tmp, (size_t)max_frames * in_h * out_w * c);
@@ -182,6 +339,10 @@ IMGXF_API int imgxf_lanczos_plan_destroy(imgxf_lanczos_plan* p) {
     if (p->d_kk_x) (void)hipFree(p->d_kk_x);
     if (p->d_bounds_y) (void)hipFree(p->d_bounds_y);
     if (p->d_kk_y) (void)hipFree(p->d_kk_y);
+    if (p->d_start_x) (void)hipFree(p->d_start_x);
+    if (p->d_pk_x) (void)hipFree(p->d_pk_x);
+    if (p->d_start_y) (void)hipFree(p->d_start_y);
+    if (p->d_pk_y) (void)hipFree(p->d_pk_y);
     if (p->d_tmp) (void)hipFree(p->d_tmp);
     delete p;
     return IMGXF_OK;
@@ -208,13 +369,19 @@ IMGXF_API int imgxf_resize_lanczos_u8(const imgxf_lanczos_plan* p, const imgxf_v
         }
         return IMGXF_OK;
     }
-    if (p->need_h && !p->need_v) return launch_h(s, d, p->d_bounds_x, p->d_kk_x, p->ksx, st);
+    static const bool slow = getenv("IMGXF_LANCZOS_SLOW") != nullptr;
+    auto run_h = [&](const View& a, const View& b) {
+        if (p->kpx && !slow) return launch_h_fast(p, a, b, st);
+        return launch_h(a, b, p->d_bounds_x, p->d_kk_x, p->ksx, st);
+    };
+    if (p->need_h && !p->need_v) return run_h(s, d);
     View mid = s;
     if (p->need_h) {
         mid.p = p->d_tmp; mid.n = s.n; mid.h = p->in_h; mid.w = p->out_w; mid.c = p->c;
         mid.rs = (int64_t)p->out_w * p->c; mid.fs = mid.rs * p->in_h;
-        IMGXF_CHECK(launch_h(s, mid, p->d_bounds_x, p->d_kk_x, p->ksx, st));
+        IMGXF_CHECK(run_h(s, mid));
     }
+    if (!slow && v_fast_ok(p, mid, d)) return launch_v_fast(p, mid, d, st);
     const int64_t total = (int64_t)d.n * d.h * d.rowbytes();
     hipLaunchKernelGGL(resample_v_kernel, dim3(grid_for(total)), dim3(256), 0, st, mid, d,
                        p->d_bounds_y, p->d_kk_y, p->ksy);

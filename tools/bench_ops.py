@@ -54,3 +54,27 @@ if what in ("point", "all"):
     report("brightness (blend const)", timeit(lambda: _ffi.call("imgxf_blend_u8", None, fill, _ffi.vp(vs), None, _ffi.vp(vo), 1.05, st)), 6.0)
     report("scale_abs", timeit(lambda: _ffi.call("imgxf_scale_abs_u8", _ffi.vp(vs), _ffi.vp(vo), 0.7, 0.0, st)), 6.0)
     report("memcpy d2d (torch copy_)", timeit(lambda: out.copy_(frames)), 6.0)
+
+if what in ("lanczos", "all"):
+    Fs = min(F, 16)
+    sub = frames[:Fs]
+    for sc in (1.1, 0.9, 1.5):
+        nw, nh = int(W * sc), int(H * sc)
+        ops.resize_lanczos(sub, (nw, nh))          # plan creation outside the timing
+        ms = timeit(lambda: ops.resize_lanczos(sub, (nw, nh)), 5)
+        opx = Fs * nw * nh
+        print(f"lanczos x{sc:<4} ({Fs} frames)          {ms:8.3f} ms  {Fs*H*W/ms/1e3:10.0f} Mpix/s(in)  {(3*Fs*H*W + 3*opx)/ms/1e6:8.1f} GB/s(in+out)", flush=True)
+if what in ("misc", "all"):
+    Fs = min(F, 16)
+    sub = frames[:Fs]
+    ms = timeit(lambda: ops.affine(sub, (1, 0.3, -648, 0, 1, 0), (W + 648, H), ops.BICUBIC, (255, 255, 255)), 3)
+    print(f"shear 0.3 bicubic ({Fs} frames)        {ms:8.3f} ms  {Fs*H*W/ms/1e3:10.0f} Mpix/s", flush=True)
+    noise = torch.randn(sub.shape, device=dev) * 12.0
+    ms = timeit(lambda: ops.add_noise(sub, noise), 5)
+    print(f"add_noise ({Fs} frames)                {ms:8.3f} ms  {Fs*H*W/ms/1e3:10.0f} Mpix/s  {18*Fs*H*W/ms/1e6:8.1f} GB/s", flush=True)
+    g = ops.rgb2l(sub)
+    ms = timeit(lambda: ops.percentile_mask(ops.sobel(g), 70), 5)
+    print(f"sobel + percentile mask ({Fs} frames)  {ms:8.3f} ms  {Fs*H*W/ms/1e3:10.0f} Mpix/s", flush=True)
+    m = ops.percentile_mask(ops.sobel(g), 70)
+    ms = timeit(lambda: ops.dilate_cross(m, 3), 5)
+    print(f"dilate_cross 3 ({Fs} frames)           {ms:8.3f} ms  {Fs*H*W/ms/1e3:10.0f} Mpix/s", flush=True)
