@@ -64,7 +64,10 @@ __device__ __forceinline__ typename A::T cubic(typename A::T v1, typename A::T v
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-template <int C, int FILTER, class A>
+// HONLY (BICUBIC): the matrix is a pure horizontal shear/shift (m3 == 0, m4 == 1, m5 integral),
+// so yin - 0.5 is an integer, dy == 0 exactly and libImaging's column cubic p1 + 0*(...) returns
+// the row-y value bit-for-bit: only row y's horizontal cubic is evaluated (apply_shear).
+template <int C, int FILTER, class A, bool HONLY = false>
 __global__ __launch_bounds__(256) void affine_kernel(View s, View d, AffineParams P, View dbg) {
     typedef typename A::T T;
     const int xg = blockIdx.x * 64 + threadIdx.x;   // group of 4 output pixels
@@ -121,9 +124,9 @@ __global__ __launch_bounds__(256) void affine_kernel(View s, View d, AffineParam
                     for (int t = 0; t < 4; ++t) xs[t] = clampi(xi - 1 + t, 0, s.w - 1) * C;
                     T rowv[4][C];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = (HONLY ? 1 : 0); t < (HONLY ? 2 : 4); ++t) {
                         const int yy = yi - 1 + t;
-                        const bool inr = (t == 0) || (yy >= 0 && yy < s.h);
+                        const bool inr = (t == 0) || HONLY || (yy >= 0 && yy < s.h);
                         const u8* r = sp + (int64_t)clampi(yy, 0, s.h - 1) * s.rs;
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void affine_kernel(View s, View d, AffineParam
                     }
 #pragma unroll
                     for (int j = 0; j < C; ++j) {
-                        v[j] = cubic<A>(rowv[0][j], rowv[1][j], rowv[2][j], rowv[3][j], dy);
+                        v[j] = HONLY ? rowv[1][j] : cubic<A>(rowv[0][j], rowv[1][j], rowv[2][j], rowv[3][j], dy);
                         px[j] = v[j] <= (T)0 ? (u8)0 : (v[j] >= (T)255 ? (u8)255 : (u8)(int)v[j]);
                     }
                 }
@@ -706,9 +709,12 @@ static int launch_affine_filter(int filter, const View& s, const View& d, const 
         case IMGXF_FILTER_BILINEAR:
             hipLaunchKernelGGL((affine_kernel<C, IMGXF_FILTER_BILINEAR, A>), grid, block, 0, st, s, d, P, dbg);
             break;
-        case IMGXF_FILTER_BICUBIC:
-            hipLaunchKernelGGL((affine_kernel<C, IMGXF_FILTER_BICUBIC, A>), grid, block, 0, st, s, d, P, dbg);
+        case IMGXF_FILTER_BICUBIC: {
+            const bool honly = P.m[3] == 0.0 && P.m[4] == 1.0 && P.m[5] == floor(P.m[5]) && fabs(P.m[5]) < 1.0e9;
+            if (honly) hipLaunchKernelGGL((affine_kernel<C, IMGXF_FILTER_BICUBIC, A, true>), grid, block, 0, st, s, d, P, dbg);
+            else hipLaunchKernelGGL((affine_kernel<C, IMGXF_FILTER_BICUBIC, A>), grid, block, 0, st, s, d, P, dbg);
             break;
+        }
         default: return IMGXF_ERR_ARG;
     }
     return launch_status();
