@@ -30,8 +30,9 @@ inline View make_view(const imgxf_view* v) {
 
 // Validate one view: non-null, positive dims, strides large enough for `elem` bytes/sample.
 inline int check_view(const imgxf_view* v, int elem = 1) {
-    if (!v || !v->data) return IMGXF_ERR_NULL;
+    if (!v) return IMGXF_ERR_NULL;
     if (v->n < 0 || v->h < 0 || v->w < 0 || v->c < 1 || v->c > 4) return IMGXF_ERR_SHAPE;
+    if (!v->data && v->n != 0 && v->h != 0 && v->w != 0) return IMGXF_ERR_NULL;   // empty views may be NULL
     if (v->w > 32767 || v->h > 32767) return IMGXF_ERR_SHAPE; // 16.16 fixed-point samplers
     int64_t rb = (int64_t)v->w * v->c * elem;
     if (v->row_stride < rb) return IMGXF_ERR_SHAPE;

