@@ -7,7 +7,13 @@ per-pixel transform hot path of aaryaamoharir/ImageTransformations.
 Importing the package loads libimgxf.so through ctypes and raises ImportError if it has
 not been built (`python -m imagetransformations_amd.build`).  There is no CPU fallback.
 """
-from . import _ffi  # noqa: F401  (fails loudly when the HIP library is missing)
+import sys as _sys
+
+# `python -m imagetransformations_amd.build` must be able to (re)build a missing or stale
+# library, so that one entry point skips the eager load; every other import fails loudly.
+_building = "imagetransformations_amd.build" in getattr(_sys, "orig_argv", [])
+if not _building:
+    from . import _ffi  # noqa: F401  (raises ImportError / AttributeError when the HIP library is missing or stale)
 
 __version__ = "0.1.0"
 __all__ = ["ops", "transformation", "sharding", "_ffi"]

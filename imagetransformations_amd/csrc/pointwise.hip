@@ -234,6 +234,132 @@ __global__ __launch_bounds__(256) void composite_kernel(View a, View b, View m, 
     }
 }
 
+// ---------------- ImageEnhance.Color: blend(L replicated, image, factor), fused ----------------
+// (/root/reference/pipenline/cifar_image_transformations.py:102-106)
+__global__ __launch_bounds__(256) void enhance_color_kernel(View s, View d, float factor) {
+    const int ngrp = (d.w + 15) >> 4;
+    const int64_t total = (int64_t)d.n * d.h * ngrp;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int g = (int)(t % ngrp);
+        const int64_t r = t / ngrp;
+        const int y = (int)(r % d.h), f = (int)(r / d.h);
+        const int x0 = g << 4;
+        const int np = min(16, d.w - x0);
+        const u8* sp = s.row(f, y) + x0 * 3;
+        u8* dp = d.row(f, y) + x0 * 3;
+        u32 in[12], out[12];
+        const bool vec = np == 16 && ((((uintptr_t)sp) | ((uintptr_t)dp)) & 15) == 0;
+        if (vec) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const uint4 q = ((const uint4*)sp)[b];
+                in[4 * b] = q.x; in[4 * b + 1] = q.y; in[4 * b + 2] = q.z; in[4 * b + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) in[k] = 0;
+            for (int e = 0; e < np * 3; ++e) {
+                const u32 v = sp[e];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) if ((e >> 2) == k) in[k] |= v << (8 * (e & 3));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) out[k] = 0;
+#pragma unroll
+        for (int px = 0; px < 16; ++px) {
+            u32 ch[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const int b = px * 3 + j; ch[j] = (in[b >> 2] >> (8 * (b & 3))) & 0xffu; }
+            const float L = (float)((ch[0] * 19595u + ch[1] * 38470u + ch[2] * 7471u + 0x8000u) >> 16);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int b = px * 3 + j;
+                const float tv = L + factor * ((float)ch[j] - L);          // Blend.c, un-contracted
+                out[b >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(floorf(tv), b & 3, out[b >> 2]);
+            }
+        }
+        if (vec) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) ((uint4*)dp)[b] = make_uint4(out[4 * b], out[4 * b + 1], out[4 * b + 2], out[4 * b + 3]);
+        } else {
+            for (int e = 0; e < np * 3; ++e) {
+                u32 w = 0;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) if ((e >> 2) == k) w = out[k];
+                dp[e] = (u8)(w >> (8 * (e & 3)));
+            }
+        }
+    }
+}
+
+// ---------------- ImageEnhance.Contrast ----------------
+// (/root/reference/pipenline/cifar_image_transformations.py:81-85)
+// pass 1: per-frame sum of L (wavefront shuffle reduction, one 64-bit atomic per wave)
+template <int C>
+__global__ __launch_bounds__(256) void lum_sum_kernel(View s, unsigned long long* sums) {
+    const int f = blockIdx.y;
+    const int64_t total = (int64_t)s.h * s.w;
+    u32 part = 0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int x = (int)(t % s.w), y = (int)(t / s.w);
+        const u8* p = s.row(f, y) + x * C;
+        part += C == 1 ? (u32)p[0] : ((u32)p[0] * 19595u + (u32)p[1] * 38470u + (u32)p[2] * 7471u + 0x8000u) >> 16;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[f], (unsigned long long)part);
+}
+
+// pass 2: blend(solid int(mean + 0.5), image, factor); the mean is formed from the frame's sum
+struct ContrastOp {
+    float factor, mean;
+    __device__ __forceinline__ float operator()(float pa, float, int) const {
+        return floorf(mean + factor * (pa - mean));
+    }
+};
+template <int C>
+__global__ __launch_bounds__(256) void contrast_kernel(View s, View d, float factor, const unsigned long long* sums) {
+    constexpr int NV = (C == 3) ? 3 : 1, CB = 16 * NV;
+    const int rowbytes = d.w * C;
+    const int nchunks = (rowbytes + CB - 1) / CB;
+    const int f = blockIdx.y;
+    const double cnt = (double)((int64_t)s.h * s.w);
+    const float mean = (float)(int)((double)sums[f] / cnt + 0.5);        // int(ImageStat.mean[0] + 0.5)
+    const int64_t total = (int64_t)d.h * nchunks;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(t % nchunks), y = (int)(t / nchunks);
+        const int xb = ck * CB;
+        const u8* ap = s.row(f, y) + xb;
+        u8* dp = d.row(f, y) + xb;
+        const int nv = min(CB, rowbytes - xb);
+        if (nv == CB && ((((uintptr_t)dp) | ((uintptr_t)ap)) & 15) == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const uint4 q = ((const uint4*)ap)[k];
+                const u32 w[4] = {q.x, q.y, q.z, q.w};
+                u32 o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u32 acc = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pa = (float)((w[i] >> (8 * e)) & 0xffu);
+                        acc = __builtin_amdgcn_cvt_pk_u8_f32(floorf(mean + factor * (pa - mean)), e, acc);
+                    }
+                    o[i] = acc;
+                }
+                ((uint4*)dp)[k] = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        } else {
+            for (int e = 0; e < nv; ++e) {
+                const float tv = floorf(mean + factor * ((float)ap[e] - mean));
+                dp[e] = (u8)__builtin_amdgcn_cvt_pk_u8_f32(tv, 0, 0u);
+            }
+        }
+    }
+}
+
 static inline unsigned grid_for(int64_t total) {
     int64_t blocks = (total + 255) / 256;
     return (unsigned)(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks));
@@ -340,5 +466,45 @@ IMGXF_API int imgxf_composite_u8(const imgxf_view* im1, const imgxf_view* im2,
     const View d = make_view(dst);
     hipLaunchKernelGGL(composite_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0,
                        (hipStream_t)stream, make_view(im1), make_view(im2), make_view(mask), d);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_enhance_color_u8(const imgxf_view* src, const imgxf_view* dst, float factor, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    if (!same_geometry(src, dst) || src->c != 3) return IMGXF_ERR_SHAPE;
+    if (empty_view(dst)) return IMGXF_OK;
+    const View d = make_view(dst);
+    const int64_t total = (int64_t)d.n * d.h * ((d.w + 15) >> 4);
+    hipLaunchKernelGGL(enhance_color_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, make_view(src), d, factor);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_enhance_contrast_u8(const imgxf_view* src, const imgxf_view* dst, float factor,
+                                        uint64_t* sums, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    if (!sums) return IMGXF_ERR_NULL;
+    if (!same_geometry(src, dst) || (src->c != 3 && src->c != 1)) return IMGXF_ERR_SHAPE;
+    if (empty_view(dst)) return IMGXF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)src->n * sizeof(uint64_t), st);
+    if (e != hipSuccess) return (int)e;
+    const View s = make_view(src), d = make_view(dst);
+    int64_t bx = ((int64_t)s.h * s.w + 256 * 16 - 1) / (256 * 16);
+    if (bx > 512) bx = 512;
+    if (bx < 1) bx = 1;
+    dim3 g1((unsigned)bx, (unsigned)s.n);
+    const int cb = s.c == 3 ? 48 : 16;
+    int64_t b2 = ((int64_t)d.h * ((d.rowbytes() + cb - 1) / cb) + 255) / 256;
+    if (b2 > 2048) b2 = 2048;
+    dim3 g2((unsigned)b2, (unsigned)s.n);
+    if (s.c == 3) {
+        hipLaunchKernelGGL((lum_sum_kernel<3>), g1, dim3(256), 0, st, s, (unsigned long long*)sums);
+        hipLaunchKernelGGL((contrast_kernel<3>), g2, dim3(256), 0, st, s, d, factor, (const unsigned long long*)sums);
+    } else {
+        hipLaunchKernelGGL((lum_sum_kernel<1>), g1, dim3(256), 0, st, s, (unsigned long long*)sums);
+        hipLaunchKernelGGL((contrast_kernel<1>), g2, dim3(256), 0, st, s, d, factor, (const unsigned long long*)sums);
+    }
     return launch_status();
 }

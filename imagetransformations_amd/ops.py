@@ -323,6 +323,25 @@ def brightness(t: torch.Tensor, factor: float) -> torch.Tensor:
     return blend((0, 0, 0, 0), t, factor)
 
 
+def enhance_color(t: torch.Tensor, factor: float) -> torch.Tensor:
+    """ImageEnhance.Color(img).enhance(factor) — cifar_image_transformations.py:102-106."""
+    t = _check_u8(t)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_enhance_color_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(factor), _stream())
+    return out
+
+
+def enhance_contrast(t: torch.Tensor, factor: float) -> torch.Tensor:
+    """ImageEnhance.Contrast(img).enhance(factor) — cifar_image_transformations.py:81-85."""
+    t = _check_u8(t)
+    n = t.shape[0] if t.dim() == 4 else 1
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    sums = torch.empty(max(n, 1), dtype=torch.int64, device=t.device)
+    F.call("imgxf_enhance_contrast_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(factor),
+           sums.data_ptr(), _stream())
+    return out
+
+
 def add_noise(t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
     """np.clip(img.astype(f32) + noise, 0, 255).astype(u8) — transformation.py:275-278."""
     t = _check_u8(t)

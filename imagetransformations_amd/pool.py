@@ -1,8 +1,8 @@
 """`TransformationPool` members that sit on the hot path, with the
 reference's static-method style and argument meaning
 (/root/reference/pipenline/cifar_image_transformations.py:37-129).  The remaining members
-(Pillow GaussianBlur box approximation, ImageEnhance.Contrast/Color/Sharpness, histogram
-equalisation, impulse / shot noise) are SURVEY §8f "next" rows and are not provided yet:
+(Pillow GaussianBlur box approximation, ImageEnhance.Sharpness, histogram
+equalisation, impulse / shot / float64 gaussian noise) are SURVEY §8f "next" rows and are not provided yet:
 asking for them raises AttributeError rather than silently running on the CPU."""
 from __future__ import annotations
 
@@ -24,6 +24,22 @@ class TransformationPool:
         kernel[int((size - 1) / 2), :] = np.ones(size)
         kernel = kernel / size
         return _download(ops.conv2d(_upload(image), kernel.tolist()))
+
+    def enhance_contrast(image, factor=None):
+        """cifar_image_transformations.py:81-85: ImageEnhance.Contrast(image).enhance(factor)."""
+        if factor is None:
+            factor = random.uniform(0.5, 2.0)
+        if image.mode not in ("RGB", "L"):
+            raise NotImplementedError(f"enhance_contrast supports RGB and L images, got {image.mode!r}")
+        return _download(ops.enhance_contrast(_upload(image), factor))
+
+    def enhance_color(image, factor=None):
+        """cifar_image_transformations.py:102-106: ImageEnhance.Color(image).enhance(factor)."""
+        if factor is None:
+            factor = random.uniform(0.5, 2.0)
+        if image.mode != "RGB":
+            raise NotImplementedError(f"enhance_color supports RGB images, got {image.mode!r}")
+        return _download(ops.enhance_color(_upload(image), factor))
 
     def enhance_brightness(image, factor=None):
         """cifar_image_transformations.py:89-93: ImageEnhance.Brightness(image).enhance(factor)."""

@@ -147,6 +147,16 @@ int imgxf_permute_u8(const imgxf_view* src, const imgxf_view* dst, const int32_t
 int imgxf_composite_u8(const imgxf_view* im1, const imgxf_view* im2, const imgxf_view* mask,
                        const imgxf_view* dst, void* stream);
 
+/* ---- ImageEnhance.Color / .Contrast ---------------------------------
+ * pipenline/cifar_image_transformations.py:81-85,102-106.  Both are Image.blend(degenerate,
+ * image, factor) with the Blend.c float semantics above.
+ * Color: degenerate = convert('L') replicated to RGB (fused per pixel).  c == 3.
+ * Contrast: degenerate = solid int(mean(L) + 0.5) per frame; `sums` is device scratch of n
+ * uint64 (zeroed by the call) that receives every frame's sum of L.  c in {1,3}. */
+int imgxf_enhance_color_u8(const imgxf_view* src, const imgxf_view* dst, float factor, void* stream);
+int imgxf_enhance_contrast_u8(const imgxf_view* src, const imgxf_view* dst, float factor,
+                              uint64_t* sums, void* stream);
+
 /* ---- crop / paste / fill (Image.crop, Image.paste, Image.new) transformation.py:187-193,287-305 */
 /* Fill every pixel of dst with color[c] (HOST pointer). */
 int imgxf_fill_u8(const imgxf_view* dst, const uint8_t* color, void* stream);

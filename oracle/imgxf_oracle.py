@@ -254,6 +254,24 @@ def permute_channels(img, perm):
     return np.ascontiguousarray(np.asarray(img)[..., list(perm)])
 
 
+def enhance_color(img, factor):
+    """ImageEnhance.Color(img).enhance(factor) (cifar_image_transformations.py:102-106):
+    degenerate = img.convert('L').convert('RGB'); Image.blend(degenerate, img, factor)."""
+    a = np.asarray(img)
+    g = rgb2l(a)
+    return blend(np.repeat(g[:, :, None], 3, axis=2), a, factor)
+
+
+def enhance_contrast(img, factor):
+    """ImageEnhance.Contrast(img).enhance(factor) (cifar_image_transformations.py:81-85):
+    degenerate = solid int(mean(L) + 0.5); Image.blend(degenerate, img, factor)."""
+    a = np.asarray(img)
+    g = rgb2l(a) if a.ndim == 3 else a
+    mean = int(int(g.astype(np.int64).sum()) / g.size + 0.5)
+    deg = np.full_like(a, mean)
+    return blend(deg, a, factor)
+
+
 # ----------------------------------------------------------------------------
 # a2 / a2' / shear: Pillow affine transform (libImaging Geometry.c)
 # ----------------------------------------------------------------------------

@@ -177,3 +177,19 @@ def test_transformation_pool_members(device):
                               np.asarray(ImageEnhance.Brightness(img).enhance(f)))
     with pytest.raises(AttributeError):
         TransformationPool.histogram_equalization(img)    # "next" tier: absent, not a CPU fallback
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (37, 61), (334, 500), (270, 480)])
+def test_enhance_color_and_contrast_bit_exact(device, hw):
+    """ImageEnhance.Color / .Contrast through the pool façade vs Pillow."""
+    from imagetransformations_amd.pool import TransformationPool
+    ImageEnhance = pytest.importorskip("PIL.ImageEnhance")
+    a = synth(7, *hw)
+    img = Image.fromarray(a)
+    for f in (0.0, 0.5, 0.73, 1.0, 1.37, 2.0):
+        assert np.array_equal(np.asarray(TransformationPool.enhance_color(img, f)), np.asarray(ImageEnhance.Color(img).enhance(f))), f
+        assert np.array_equal(np.asarray(TransformationPool.enhance_contrast(img, f)), np.asarray(ImageEnhance.Contrast(img).enhance(f))), f
+        assert np.array_equal(np.asarray(TransformationPool.enhance_color(img, f)), O.enhance_color(a, f))
+        assert np.array_equal(np.asarray(TransformationPool.enhance_contrast(img, f)), O.enhance_contrast(a, f))
+    gray = img.convert("L")
+    assert np.array_equal(np.asarray(TransformationPool.enhance_contrast(gray, 1.4)), np.asarray(ImageEnhance.Contrast(gray).enhance(1.4)))

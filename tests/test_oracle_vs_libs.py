@@ -69,6 +69,15 @@ def test_colour_and_mask_ops(hw):
         assert np.array_equal(O.blend(a, b2, alpha), np.asarray(Image.blend(img, Image.fromarray(b2), alpha))), alpha
 
 
+@pytest.mark.parametrize("hw", SIZES)
+def test_enhance_color_contrast(hw):
+    a = synth(6, *hw)
+    img = Image.fromarray(a)
+    for f in (0.0, 0.5, 0.73, 1.0, 1.37, 2.0):
+        assert np.array_equal(O.enhance_color(a, f), np.asarray(ImageEnhance.Color(img).enhance(f))), f
+        assert np.array_equal(O.enhance_contrast(a, f), np.asarray(ImageEnhance.Contrast(img).enhance(f))), f
+
+
 def test_c_oracle_matches_numpy_oracle():
     """The plain-C restatement (cpu_baseline leg of bench.py) equals the NumPy oracle."""
     from oracle import c_oracle as CO
