@@ -98,9 +98,64 @@ __global__ __launch_bounds__(256) void sobel_kernel(View s, View d, int variant)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// libImaging ImagingFilter3x3 (Image.filter with a 3x3 ImageFilter.Kernel, e.g. SMOOTH behind
+// ImageEnhance.Sharpness, cifar_image_transformations.py:95-99): float32, the exact operation
+// order of Filter.c, the one-pixel frame copied from the input.  A lane owns 4 bytes of a row.
+// ---------------------------------------------------------------------------------------
+struct K9 { float k[9]; float off; };
+__global__ __launch_bounds__(256) void filter3x3_kernel(View s, View d, K9 K) {
+    const int C = s.c;
+    const int rowbytes = s.w * C;
+    const int nq = (rowbytes + 3) >> 2;
+    const int64_t total = (int64_t)s.n * s.h * nq;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int qd = (int)(t % nq);
+        const int64_t r = t / nq;
+        const int y = (int)(r % s.h), f = (int)(r / s.h);
+        const u8* r0 = s.row(f, y);
+        const bool inner_row = y > 0 && y < s.h - 1 && s.w >= 3;
+        const u8* rm = inner_row ? s.row(f, y - 1) : r0;
+        const u8* rp = inner_row ? s.row(f, y + 1) : r0;
+        u8* dp = d.row(f, y);
+        for (int e = 0; e < 4; ++e) {
+            const int b = qd * 4 + e;
+            if (b >= rowbytes) break;
+            u8 v = r0[b];
+            if (inner_row && b >= C && b < rowbytes - C) {
+                float ss = K.off;
+                ss += ((float)rp[b - C] * K.k[0] + (float)rp[b] * K.k[1]) + (float)rp[b + C] * K.k[2];
+                ss += ((float)r0[b - C] * K.k[3] + (float)r0[b] * K.k[4]) + (float)r0[b + C] * K.k[5];
+                ss += ((float)rm[b - C] * K.k[6] + (float)rm[b] * K.k[7]) + (float)rm[b + C] * K.k[8];
+                v = ss <= 0.0f ? (u8)0 : (ss >= 255.0f ? (u8)255 : (u8)(int)ss);
+            }
+            dp[b] = v;
+        }
+    }
+}
+
 } // namespace imgxf
 
 using namespace imgxf;
+
+IMGXF_API int imgxf_filter3x3_u8(const imgxf_view* src, const imgxf_view* dst, const float* kernel9,
+                                 float scale, float offset, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    if (!kernel9) return IMGXF_ERR_NULL;
+    if (!same_geometry(src, dst)) return IMGXF_ERR_SHAPE;
+    if (scale == 0.0f) return IMGXF_ERR_ARG;
+    if (empty_view(src)) return IMGXF_OK;
+    K9 K;
+    for (int i = 0; i < 9; ++i) K.k[i] = kernel9[i] / scale;      // FLOAT32 division, as _imaging.c does
+    K.off = offset + 0.5f;
+    const View s = make_view(src), d = make_view(dst);
+    const int64_t total = (int64_t)s.n * s.h * ((s.rowbytes() + 3) >> 2);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(filter3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, d, K);
+    return launch_status();
+}
 
 IMGXF_API int imgxf_conv2d_u8(const imgxf_view* src, const imgxf_view* dst, const float* kernel,
                               int kh, int kw, int border, void* stream) {

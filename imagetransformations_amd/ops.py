@@ -323,6 +323,26 @@ def brightness(t: torch.Tensor, factor: float) -> torch.Tensor:
     return blend((0, 0, 0, 0), t, factor)
 
 
+SMOOTH_KERNEL = (1, 1, 1, 1, 5, 1, 1, 1, 1)      # ImageFilter.SMOOTH (scale 13)
+
+
+def filter3x3(t: torch.Tensor, kernel9: Sequence[float], scale: float, offset: float = 0.0) -> torch.Tensor:
+    """Image.filter(ImageFilter.Kernel((3, 3), kernel9, scale, offset)) — libImaging ImagingFilter3x3."""
+    t = _check_u8(t)
+    if len(kernel9) != 9:
+        raise ValueError("not enough coefficients in kernel")      # Pillow's message
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_filter3x3_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(kernel9), float(scale),
+           float(offset), _stream())
+    return out
+
+
+def enhance_sharpness(t: torch.Tensor, factor: float) -> torch.Tensor:
+    """ImageEnhance.Sharpness(img).enhance(factor) = blend(img.filter(SMOOTH), img, factor)."""
+    t = _check_u8(t)
+    return blend(filter3x3(t, SMOOTH_KERNEL, 13.0), t, factor)
+
+
 def enhance_color(t: torch.Tensor, factor: float) -> torch.Tensor:
     """ImageEnhance.Color(img).enhance(factor) — cifar_image_transformations.py:102-106."""
     t = _check_u8(t)

@@ -1,7 +1,7 @@
 """`TransformationPool` members that sit on the hot path, with the
 reference's static-method style and argument meaning
 (/root/reference/pipenline/cifar_image_transformations.py:37-129).  The remaining members
-(Pillow GaussianBlur box approximation, ImageEnhance.Sharpness, histogram
+(Pillow GaussianBlur box approximation, histogram
 equalisation, impulse / shot / float64 gaussian noise) are SURVEY §8f "next" rows and are not provided yet:
 asking for them raises AttributeError rather than silently running on the CPU."""
 from __future__ import annotations
@@ -32,6 +32,14 @@ class TransformationPool:
         if image.mode not in ("RGB", "L"):
             raise NotImplementedError(f"enhance_contrast supports RGB and L images, got {image.mode!r}")
         return _download(ops.enhance_contrast(_upload(image), factor))
+
+    def enhance_sharpness(image, factor=None):
+        """cifar_image_transformations.py:95-99: ImageEnhance.Sharpness(image).enhance(factor)."""
+        if factor is None:
+            factor = random.uniform(0.5, 3.0)
+        if image.mode not in ("RGB", "L"):
+            raise NotImplementedError(f"enhance_sharpness supports RGB and L images, got {image.mode!r}")
+        return _download(ops.enhance_sharpness(_upload(image), factor))
 
     def enhance_color(image, factor=None):
         """cifar_image_transformations.py:102-106: ImageEnhance.Color(image).enhance(factor)."""

@@ -147,6 +147,14 @@ int imgxf_permute_u8(const imgxf_view* src, const imgxf_view* dst, const int32_t
 int imgxf_composite_u8(const imgxf_view* im1, const imgxf_view* im2, const imgxf_view* mask,
                        const imgxf_view* dst, void* stream);
 
+/* ---- Image.filter(ImageFilter.Kernel((3,3), kernel, scale, offset)) — libImaging ImagingFilter3x3
+ * (ImageFilter.SMOOTH behind ImageEnhance.Sharpness, cifar_image_transformations.py:95-99):
+ * float32 coefficients kernel9[i]/scale (HOST pointer, Pillow's order: first triple = row y+1),
+ * ss = offset + 0.5 then one (a*k0 + b*k1) + c*k2 per row, clip8 truncation; the one-pixel
+ * frame of the image is copied from the input.  Any c. */
+int imgxf_filter3x3_u8(const imgxf_view* src, const imgxf_view* dst, const float* kernel9,
+                       float scale, float offset, void* stream);
+
 /* ---- ImageEnhance.Color / .Contrast ---------------------------------
  * pipenline/cifar_image_transformations.py:81-85,102-106.  Both are Image.blend(degenerate,
  * image, factor) with the Blend.c float semantics above.

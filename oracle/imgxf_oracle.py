@@ -254,6 +254,40 @@ def permute_channels(img, perm):
     return np.ascontiguousarray(np.asarray(img)[..., list(perm)])
 
 
+def filter3x3(img, kernel9, scale, offset=0.0):
+    """Image.filter(ImageFilter.Kernel((3,3), kernel9, scale, offset)) — libImaging
+    ImagingFilter3x3: float32 coefficients kernel/scale, ss = offset + 0.5, then one
+    `(a*k0 + b*k1) + c*k2` per row (row y+1 first), clip8 truncation; the 1-pixel frame
+    is copied from the input."""
+    a = np.asarray(img)
+    k = (np.asarray(kernel9, np.float32) / np.float32(scale)).astype(np.float32)
+    h, w = a.shape[:2]
+    out = a.copy()
+    if h < 3 or w < 3:
+        return out
+    f = a.astype(np.float32)
+
+    def row3(r, kk):
+        return (r[:, :-2] * kk[0] + r[:, 1:-1] * kk[1]) + r[:, 2:] * kk[2]
+
+    ss = (np.float32(offset) + np.float32(0.5)) + row3(f[2:], k[0:3])
+    ss = ss + row3(f[1:-1], k[3:6])
+    ss = ss + row3(f[:-2], k[6:9])
+    q = np.where(ss <= 0, 0, np.where(ss >= 255, 255, ss.astype(np.int32))).astype(np.uint8)
+    out[1:-1, 1:-1] = q
+    return out
+
+
+SMOOTH_KERNEL = (1, 1, 1, 1, 5, 1, 1, 1, 1)   # ImageFilter.SMOOTH, scale 13
+
+
+def enhance_sharpness(img, factor):
+    """ImageEnhance.Sharpness(img).enhance(factor) (cifar_image_transformations.py:95-99):
+    Image.blend(img.filter(ImageFilter.SMOOTH), img, factor)."""
+    a = np.asarray(img)
+    return blend(filter3x3(a, SMOOTH_KERNEL, 13), a, factor)
+
+
 def enhance_color(img, factor):
     """ImageEnhance.Color(img).enhance(factor) (cifar_image_transformations.py:102-106):
     degenerate = img.convert('L').convert('RGB'); Image.blend(degenerate, img, factor)."""

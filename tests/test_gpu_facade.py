@@ -193,3 +193,21 @@ def test_enhance_color_and_contrast_bit_exact(device, hw):
         assert np.array_equal(np.asarray(TransformationPool.enhance_contrast(img, f)), O.enhance_contrast(a, f))
     gray = img.convert("L")
     assert np.array_equal(np.asarray(TransformationPool.enhance_contrast(gray, 1.4)), np.asarray(ImageEnhance.Contrast(gray).enhance(1.4)))
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (37, 61), (334, 500), (3, 3), (2, 5)])
+def test_filter3x3_and_sharpness_bit_exact(device, hw):
+    import torch
+    from imagetransformations_amd import ops
+    from imagetransformations_amd.pool import TransformationPool
+    ImageEnhance = pytest.importorskip("PIL.ImageEnhance")
+    ImageFilter = pytest.importorskip("PIL.ImageFilter")
+    a = synth(8, *hw)
+    img = Image.fromarray(a)
+    t = torch.from_numpy(a).to(device)
+    assert np.array_equal(ops.filter3x3(t, ops.SMOOTH_KERNEL, 13).cpu().numpy(), np.asarray(img.filter(ImageFilter.SMOOTH)))
+    assert np.array_equal(ops.filter3x3(t, (-2, -2, -2, -2, 32, -2, -2, -2, -2), 16).cpu().numpy(),
+                          np.asarray(img.filter(ImageFilter.SHARPEN)))
+    for f in (0.5, 1.0, 2.1, 3.0):
+        assert np.array_equal(np.asarray(TransformationPool.enhance_sharpness(img, f)),
+                              np.asarray(ImageEnhance.Sharpness(img).enhance(f))), f

@@ -78,6 +78,18 @@ def test_enhance_color_contrast(hw):
         assert np.array_equal(O.enhance_contrast(a, f), np.asarray(ImageEnhance.Contrast(img).enhance(f))), f
 
 
+@pytest.mark.parametrize("hw", SIZES + [(3, 3), (2, 5)])
+def test_filter3x3_and_sharpness(hw):
+    ImageFilter = pytest.importorskip("PIL.ImageFilter")
+    a = synth(8, *hw)
+    img = Image.fromarray(a)
+    assert np.array_equal(O.filter3x3(a, O.SMOOTH_KERNEL, 13), np.asarray(img.filter(ImageFilter.SMOOTH)))
+    sharpen = (-2, -2, -2, -2, 32, -2, -2, -2, -2)          # ImageFilter.SHARPEN, scale 16
+    assert np.array_equal(O.filter3x3(a, sharpen, 16), np.asarray(img.filter(ImageFilter.SHARPEN)))
+    for f in (0.5, 1.0, 2.1, 3.0):
+        assert np.array_equal(O.enhance_sharpness(a, f), np.asarray(ImageEnhance.Sharpness(img).enhance(f))), f
+
+
 def test_c_oracle_matches_numpy_oracle():
     """The plain-C restatement (cpu_baseline leg of bench.py) equals the NumPy oracle."""
     from oracle import c_oracle as CO
