@@ -59,6 +59,8 @@ SIGNATURES = {
     "imgxf_add_noise_u8": [_VP, _VP, _VP, C.c_void_p],
     "imgxf_permute_u8": [_VP, _VP, _I32, C.c_void_p],
     "imgxf_composite_u8": [_VP, _VP, _VP, _VP, C.c_void_p],
+    "imgxf_box_blur_u8": [_VP, _VP, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p],
+    "imgxf_gaussian_blur_pil_u8": [_VP, _VP, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p],
     "imgxf_filter3x3_u8": [_VP, _VP, _F, C.c_float, C.c_float, C.c_void_p],
     "imgxf_enhance_color_u8": [_VP, _VP, C.c_float, C.c_void_p],
     "imgxf_enhance_contrast_u8": [_VP, _VP, C.c_float, C.c_void_p, C.c_void_p],

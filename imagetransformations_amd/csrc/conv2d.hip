@@ -9,6 +9,7 @@
 #include "sobel_march.inc"
 #include <string.h>
 #include <stdlib.h>
+#include <math.h>
 
 namespace imgxf {
 
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256) void sobel_kernel(View s, View d, int variant)
 // ImageEnhance.Sharpness, cifar_image_transformations.py:95-99): float32, the exact operation
 // order of Filter.c, the one-pixel frame copied from the input.  A lane owns 4 bytes of a row.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int clampi_(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 struct K9 { float k[9]; float off; };
 __global__ __launch_bounds__(256) void filter3x3_kernel(View s, View d, K9 K) {
     const int C = s.c;
@@ -134,9 +136,101 @@ __global__ __launch_bounds__(256) void filter3x3_kernel(View s, View d, K9 K) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// libImaging BoxBlur.c (ImageFilter.BoxBlur / GaussianBlur, TransformationPool.defocus_blur,
+// cifar_image_transformations.py:72-77).  One pass = ImagingLineBoxBlur: exact uint32
+// arithmetic out = (window_sum*ww + (far_l + far_r)*fw + 2^23) >> 24 with replicated edges;
+// evaluated directly per output byte (the C code's running sum gives the same integers).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void box_pass_kernel(View s, View d, int radius, u32 ww, u32 fw, int vertical) {
+    const int C = s.c;
+    const int rowbytes = s.w * C;
+    const int64_t total = (int64_t)s.n * s.h * rowbytes;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int b = (int)(t % rowbytes);
+        const int64_t r = t / rowbytes;
+        const int y = (int)(r % s.h), f = (int)(r / s.h);
+        u32 acc = 0, far;
+        if (!vertical) {
+            const u8* rp = s.row(f, y);
+            const int x = b / C, ch = b - x * C;
+            for (int i = -radius; i <= radius; ++i) acc += rp[clampi_(x + i, 0, s.w - 1) * C + ch];
+            far = (u32)rp[clampi_(x - radius - 1, 0, s.w - 1) * C + ch] + (u32)rp[clampi_(x + radius + 1, 0, s.w - 1) * C + ch];
+        } else {
+            for (int i = -radius; i <= radius; ++i) acc += s.row(f, clampi_(y + i, 0, s.h - 1))[b];
+            far = (u32)s.row(f, clampi_(y - radius - 1, 0, s.h - 1))[b] + (u32)s.row(f, clampi_(y + radius + 1, 0, s.h - 1))[b];
+        }
+        const u32 bulk = acc * ww + far * fw;
+        d.row(f, y)[b] = (u8)((bulk + (1u << 23)) >> 24);
+    }
+}
+
 } // namespace imgxf
 
 using namespace imgxf;
+
+// BoxBlur.c _gaussian_blur_radius: float variables, double sqrt / floor (built un-contracted)
+static float gaussian_box_radius(float radius, int passes) {
+    float sigma2, L, l, a;
+    sigma2 = radius * radius / passes;
+    L = sqrt(12.0 * sigma2 + 1.0);
+    l = floor((L - 1.0) / 2.0);
+    a = (2 * l + 1) * (l * (l + 1) - 3 * sigma2);
+    a /= 6 * (sigma2 - (l + 1) * (l + 1));
+    return l + a;
+}
+
+IMGXF_API int imgxf_box_blur_u8(const imgxf_view* src, const imgxf_view* dst, float xradius, float yradius,
+                                int passes, void* workspace, size_t workspace_bytes, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    if (!same_geometry(src, dst)) return IMGXF_ERR_SHAPE;
+    if (passes < 1 || passes > 16 || !(xradius >= 0.0f) || !(yradius >= 0.0f) || xradius > 16384.f || yradius > 16384.f)
+        return IMGXF_ERR_ARG;
+    if (empty_view(src)) return IMGXF_OK;
+    const View s = make_view(src), d = make_view(dst);
+    const size_t need = (size_t)s.n * s.h * s.rowbytes();
+    const int total_passes = (xradius != 0.0f ? passes : 0) + (yradius != 0.0f ? passes : 0);
+    if (total_passes > 1 && (!workspace || workspace_bytes < need)) return IMGXF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    View ws = s;                       // contiguous scratch image with the same geometry
+    ws.p = (u8*)workspace; ws.rs = s.rowbytes(); ws.fs = ws.rs * s.h;
+    if (total_passes == 0) {
+        for (int f = 0; f < s.n; ++f) {
+            hipError_t e = hipMemcpy2DAsync(d.p + f * d.fs, d.rs, s.p + f * s.fs, s.rs, (size_t)s.rowbytes(), s.h,
+                                            hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return (int)e;
+        }
+        return IMGXF_OK;
+    }
+    int64_t blocks = ((int64_t)need + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    View cur = s;
+    int done = 0;
+    for (int axis = 0; axis < 2; ++axis) {
+        const float fr = axis == 0 ? xradius : yradius;
+        if (fr == 0.0f) continue;
+        const int radius = (int)fr;
+        const u32 ww = (u32)((float)(1u << 24) / (fr * 2 + 1));
+        const u32 fw = ((u32)(1 << 24) - (u32)(radius * 2 + 1) * ww) / 2;
+        for (int p = 0; p < passes; ++p) {
+            // the last pass must land in dst: alternate so that parity works out
+            const bool to_dst = ((total_passes - 1 - done) & 1) == 0;
+            const View out = to_dst ? d : ws;
+            hipLaunchKernelGGL(box_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur, out, radius, ww, fw, axis);
+            cur = out;
+            ++done;
+        }
+    }
+    return launch_status();
+}
+
+IMGXF_API int imgxf_gaussian_blur_pil_u8(const imgxf_view* src, const imgxf_view* dst, float radius,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (!(radius >= 0.0f)) return IMGXF_ERR_ARG;
+    const float r = gaussian_box_radius(radius, 3);
+    return imgxf_box_blur_u8(src, dst, r, r, 3, workspace, workspace_bytes, stream);
+}
 
 IMGXF_API int imgxf_filter3x3_u8(const imgxf_view* src, const imgxf_view* dst, const float* kernel9,
                                  float scale, float offset, void* stream) {

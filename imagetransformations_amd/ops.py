@@ -323,6 +323,28 @@ def brightness(t: torch.Tensor, factor: float) -> torch.Tensor:
     return blend((0, 0, 0, 0), t, factor)
 
 
+def box_blur(t: torch.Tensor, radius: float, passes: int = 1) -> torch.Tensor:
+    """image.filter(ImageFilter.BoxBlur(radius)) (passes=1) — libImaging ImagingBoxBlur."""
+    t = _check_u8(t)
+    if radius < 0:
+        raise ValueError("radius must be >= 0")        # Pillow's message
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    ws = torch.empty_like(out)
+    F.call("imgxf_box_blur_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(radius), float(radius), int(passes),
+           ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def gaussian_blur_pil(t: torch.Tensor, radius: float) -> torch.Tensor:
+    """image.filter(ImageFilter.GaussianBlur(radius)) — cifar_image_transformations.py:77."""
+    t = _check_u8(t)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    ws = torch.empty_like(out)
+    F.call("imgxf_gaussian_blur_pil_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(radius),
+           ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
 SMOOTH_KERNEL = (1, 1, 1, 1, 5, 1, 1, 1, 1)      # ImageFilter.SMOOTH (scale 13)
 
 

@@ -1,8 +1,7 @@
 """`TransformationPool` members that sit on the hot path, with the
 reference's static-method style and argument meaning
 (/root/reference/pipenline/cifar_image_transformations.py:37-129).  The remaining members
-(Pillow GaussianBlur box approximation, histogram
-equalisation, impulse / shot / float64 gaussian noise) are SURVEY §8f "next" rows and are not provided yet:
+(histogram equalisation, impulse / shot / float64 gaussian noise) are SURVEY §8f "next" rows and are not provided yet:
 asking for them raises AttributeError rather than silently running on the CPU."""
 from __future__ import annotations
 
@@ -24,6 +23,16 @@ class TransformationPool:
         kernel[int((size - 1) / 2), :] = np.ones(size)
         kernel = kernel / size
         return _download(ops.conv2d(_upload(image), kernel.tolist()))
+
+    def defocus_blur(image, severity=None):
+        """cifar_image_transformations.py:72-77: image.filter(ImageFilter.GaussianBlur(radius))."""
+        if severity is None:
+            severity = random.choice([1, 2, 3, 4, 5])
+        blur_levels = [3, 4, 6, 8, 10]
+        radius = blur_levels[severity - 1]
+        if image.mode not in ("RGB", "L"):
+            raise NotImplementedError(f"defocus_blur supports RGB and L images, got {image.mode!r}")
+        return _download(ops.gaussian_blur_pil(_upload(image), radius))
 
     def enhance_contrast(image, factor=None):
         """cifar_image_transformations.py:81-85: ImageEnhance.Contrast(image).enhance(factor)."""

@@ -155,6 +155,16 @@ int imgxf_composite_u8(const imgxf_view* im1, const imgxf_view* im2, const imgxf
 int imgxf_filter3x3_u8(const imgxf_view* src, const imgxf_view* dst, const float* kernel9,
                        float scale, float offset, void* stream);
 
+/* ---- ImageFilter.BoxBlur / ImageFilter.GaussianBlur — libImaging BoxBlur.c --------------------
+ * (TransformationPool.defocus_blur, cifar_image_transformations.py:72-77.)  `passes` box passes
+ * along x then along y, each in exact uint32 arithmetic with replicated edges and a uint8
+ * intermediate.  workspace: device scratch of n*h*w*c bytes (needed when more than one pass
+ * runs).  gaussian_blur_pil: box radius from Pillow's _gaussian_blur_radius, 3 passes. */
+int imgxf_box_blur_u8(const imgxf_view* src, const imgxf_view* dst, float xradius, float yradius,
+                      int passes, void* workspace, size_t workspace_bytes, void* stream);
+int imgxf_gaussian_blur_pil_u8(const imgxf_view* src, const imgxf_view* dst, float radius,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- ImageEnhance.Color / .Contrast ---------------------------------
  * pipenline/cifar_image_transformations.py:81-85,102-106.  Both are Image.blend(degenerate,
  * image, factor) with the Blend.c float semantics above.

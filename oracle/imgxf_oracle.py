@@ -281,6 +281,57 @@ def filter3x3(img, kernel9, scale, offset=0.0):
 SMOOTH_KERNEL = (1, 1, 1, 1, 5, 1, 1, 1, 1)   # ImageFilter.SMOOTH, scale 13
 
 
+def gaussian_box_radius(radius, passes=3):
+    """libImaging BoxBlur.c _gaussian_blur_radius: float32 variables, double sqrt/floor."""
+    f32 = np.float32
+    radius = f32(radius)
+    sigma2 = f32(radius * radius / f32(passes))
+    L = f32(math.sqrt(12.0 * float(sigma2) + 1.0))
+    l = f32(math.floor((float(L) - 1.0) / 2.0))
+    a = f32(f32(f32(2) * l + f32(1)) * f32(f32(l * f32(l + f32(1))) - f32(f32(3) * sigma2)))
+    a = f32(a / f32(f32(6) * f32(sigma2 - f32(f32(l + f32(1)) * f32(l + f32(1))))))
+    return f32(l + a)
+
+
+def box_blur_pass(img, float_radius, axis):
+    """One ImagingHorizontalBoxBlur pass along `axis` (1 = x, 0 = y): exact uint32 arithmetic,
+    edge pixels replicated, out = (window_sum*ww + (far_left+far_right)*fw + 2^23) >> 24."""
+    a = np.asarray(img)
+    fr = np.float32(float_radius)
+    radius = int(fr)
+    ww = int(np.float32(16777216.0) / np.float32(fr * np.float32(2) + np.float32(1))) & 0xFFFFFFFF
+    fw = ((16777216 - (radius * 2 + 1) * ww) & 0xFFFFFFFF) // 2
+    n = a.shape[axis]
+    idx = np.arange(n)
+    src = np.moveaxis(a, axis, 0).astype(np.uint64)
+    acc = np.zeros_like(src)
+    for i in range(-radius, radius + 1):
+        acc += src[np.clip(idx + i, 0, n - 1)]
+    far = src[np.clip(idx - radius - 1, 0, n - 1)] + src[np.clip(idx + radius + 1, 0, n - 1)]
+    bulk = (acc * ww + far * fw) & 0xFFFFFFFF
+    out = (((bulk + (1 << 23)) & 0xFFFFFFFF) >> 24).astype(np.uint8)
+    return np.moveaxis(out, 0, axis)
+
+
+def box_blur(img, xradius, yradius, passes=1):
+    """ImagingBoxBlur: `passes` horizontal passes, then `passes` vertical ones (ImageFilter.BoxBlur)."""
+    out = np.asarray(img)
+    if xradius != 0:
+        for _ in range(passes):
+            out = box_blur_pass(out, xradius, 1)
+    if yradius != 0:
+        for _ in range(passes):
+            out = box_blur_pass(out, yradius, 0)
+    return out if out is not img else np.array(img)
+
+
+def pil_gaussian_blur(img, radius):
+    """image.filter(ImageFilter.GaussianBlur(radius)) — TransformationPool.defocus_blur
+    (cifar_image_transformations.py:72-77): three box-blur passes per axis."""
+    r = gaussian_box_radius(radius, 3)
+    return box_blur(img, r, r, 3)
+
+
 def enhance_sharpness(img, factor):
     """ImageEnhance.Sharpness(img).enhance(factor) (cifar_image_transformations.py:95-99):
     Image.blend(img.filter(ImageFilter.SMOOTH), img, factor)."""

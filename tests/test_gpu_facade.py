@@ -211,3 +211,23 @@ def test_filter3x3_and_sharpness_bit_exact(device, hw):
     for f in (0.5, 1.0, 2.1, 3.0):
         assert np.array_equal(np.asarray(TransformationPool.enhance_sharpness(img, f)),
                               np.asarray(ImageEnhance.Sharpness(img).enhance(f))), f
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (37, 61), (5, 4), (100, 130)])
+def test_pillow_gaussian_and_box_blur_bit_exact(device, hw):
+    import torch
+    from imagetransformations_amd import ops
+    from imagetransformations_amd.pool import TransformationPool
+    ImageFilter = pytest.importorskip("PIL.ImageFilter")
+    a = synth(9, *hw)
+    img = Image.fromarray(a)
+    t = torch.from_numpy(a).to(device)
+    for r in (0.5, 1, 3, 4, 6, 8, 10, 1.7, 25):
+        assert np.array_equal(ops.gaussian_blur_pil(t, r).cpu().numpy(), np.asarray(img.filter(ImageFilter.GaussianBlur(radius=r)))), r
+    for br in (0, 1, 2.5, 7):
+        assert np.array_equal(ops.box_blur(t, br).cpu().numpy(), np.asarray(img.filter(ImageFilter.BoxBlur(br)))), br
+    for sev in (1, 3, 5):
+        assert np.array_equal(np.asarray(TransformationPool.defocus_blur(img, sev)),
+                              np.asarray(img.filter(ImageFilter.GaussianBlur(radius=[3, 4, 6, 8, 10][sev - 1]))))
+    gray = img.convert("L")
+    assert np.array_equal(np.asarray(TransformationPool.defocus_blur(gray, 2)), np.asarray(gray.filter(ImageFilter.GaussianBlur(radius=4))))

@@ -90,6 +90,17 @@ def test_filter3x3_and_sharpness(hw):
         assert np.array_equal(O.enhance_sharpness(a, f), np.asarray(ImageEnhance.Sharpness(img).enhance(f))), f
 
 
+@pytest.mark.parametrize("hw", [(32, 32), (37, 61), (5, 4), (100, 130)])
+def test_pillow_box_and_gaussian_blur(hw):
+    ImageFilter = pytest.importorskip("PIL.ImageFilter")
+    a = synth(9, *hw)
+    img = Image.fromarray(a)
+    for r in (0.5, 1, 2, 3, 4, 6, 8, 10, 1.7, 25):
+        assert np.array_equal(O.pil_gaussian_blur(a, r), np.asarray(img.filter(ImageFilter.GaussianBlur(radius=r)))), r
+    for br in (1, 2.5, 7):
+        assert np.array_equal(O.box_blur(a, np.float32(br), np.float32(br), 1), np.asarray(img.filter(ImageFilter.BoxBlur(br)))), br
+
+
 def test_c_oracle_matches_numpy_oracle():
     """The plain-C restatement (cpu_baseline leg of bench.py) equals the NumPy oracle."""
     from oracle import c_oracle as CO
