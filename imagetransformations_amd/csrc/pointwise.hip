@@ -360,6 +360,38 @@ __global__ __launch_bounds__(256) void contrast_kernel(View s, View d, float fac
     }
 }
 
+// ---------------- TransformationPool noise members (cifar_image_transformations.py:39-70) ----------------
+// The random draws stay on the host (NumPy's global generator, as in the reference); the device
+// applies them.  MODE 0: gaussian_noise  out = trunc(clip(f64(p) + z, 0, 255))          (z float64)
+//                MODE 1: shot_noise      out = trunc(clip(k / lambda * 255.0, 0, 255))   (k = Poisson draw as float64)
+template <int MODE>
+__global__ __launch_bounds__(256) void noise_f64_kernel(View s, View z, View d, double lambda) {
+    const int rowbytes = d.w * d.c;
+    const int64_t total = (int64_t)d.n * d.h * rowbytes;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int b = (int)(t % rowbytes);
+        const int64_t r = t / rowbytes;
+        const int y = (int)(r % d.h), f = (int)(r / d.h);
+        const double zv = ((const double*)z.row(f, y))[b];
+        double v = MODE == 0 ? (double)(float)s.row(f, y)[b] + zv : zv / lambda * 255.0;
+        v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);                     // np.clip
+        d.row(f, y)[b] = (u8)(int)v;                                      // astype(np.uint8)
+    }
+}
+// impulse_noise: pixels with mask < lo become 0, with mask > hi become 255 (all channels)
+__global__ __launch_bounds__(256) void impulse_kernel(View s, View m, View d, double lo, double hi) {
+    const int64_t total = (int64_t)d.n * d.h * d.w;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int x = (int)(t % d.w);
+        const int64_t r = t / d.w;
+        const int y = (int)(r % d.h), f = (int)(r / d.h);
+        const double mv = ((const double*)m.row(f, y))[x];
+        const u8* sp = s.row(f, y) + x * d.c;
+        u8* dp = d.row(f, y) + x * d.c;
+        for (int j = 0; j < d.c; ++j) dp[j] = mv < lo ? (u8)0 : (mv > hi ? (u8)255 : sp[j]);
+    }
+}
+
 static inline unsigned grid_for(int64_t total) {
     int64_t blocks = (total + 255) / 256;
     return (unsigned)(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks));
@@ -506,5 +538,45 @@ IMGXF_API int imgxf_enhance_contrast_u8(const imgxf_view* src, const imgxf_view*
         hipLaunchKernelGGL((lum_sum_kernel<1>), g1, dim3(256), 0, st, s, (unsigned long long*)sums);
         hipLaunchKernelGGL((contrast_kernel<1>), g2, dim3(256), 0, st, s, d, factor, (const unsigned long long*)sums);
     }
+    return launch_status();
+}
+
+IMGXF_API int imgxf_add_noise_f64_u8(const imgxf_view* src, const imgxf_view* noise_f64, const imgxf_view* dst, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    IMGXF_CHECK(check_view(noise_f64, 8));
+    if (!same_geometry(src, dst) || !same_geometry(src, noise_f64)) return IMGXF_ERR_SHAPE;
+    if (((uintptr_t)noise_f64->data & 7) || (noise_f64->row_stride & 7) || (noise_f64->frame_stride & 7)) return IMGXF_ERR_ARG;
+    if (empty_view(dst)) return IMGXF_OK;
+    const View d = make_view(dst);
+    hipLaunchKernelGGL((noise_f64_kernel<0>), dim3(grid_for((int64_t)d.n * d.h * d.rowbytes())), dim3(256), 0,
+                       (hipStream_t)stream, make_view(src), make_view(noise_f64), d, 1.0);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_shot_noise_u8(const imgxf_view* counts_f64, double lambda, const imgxf_view* dst, void* stream) {
+    IMGXF_CHECK(check_view(dst));
+    IMGXF_CHECK(check_view(counts_f64, 8));
+    if (!same_geometry(dst, counts_f64)) return IMGXF_ERR_SHAPE;
+    if (!(lambda > 0.0)) return IMGXF_ERR_ARG;
+    if (((uintptr_t)counts_f64->data & 7) || (counts_f64->row_stride & 7) || (counts_f64->frame_stride & 7)) return IMGXF_ERR_ARG;
+    if (empty_view(dst)) return IMGXF_OK;
+    const View d = make_view(dst);
+    hipLaunchKernelGGL((noise_f64_kernel<1>), dim3(grid_for((int64_t)d.n * d.h * d.rowbytes())), dim3(256), 0,
+                       (hipStream_t)stream, d, make_view(counts_f64), d, lambda);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_impulse_noise_u8(const imgxf_view* src, const imgxf_view* mask_f64, double lo, double hi,
+                                     const imgxf_view* dst, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    IMGXF_CHECK(check_view(mask_f64, 8));
+    if (!same_geometry(src, dst) || !same_nhw(src, mask_f64) || mask_f64->c != 1) return IMGXF_ERR_SHAPE;
+    if (((uintptr_t)mask_f64->data & 7) || (mask_f64->row_stride & 7) || (mask_f64->frame_stride & 7)) return IMGXF_ERR_ARG;
+    if (empty_view(dst)) return IMGXF_OK;
+    const View d = make_view(dst);
+    hipLaunchKernelGGL(impulse_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0, (hipStream_t)stream,
+                       make_view(src), make_view(mask_f64), d, lo, hi);
     return launch_status();
 }

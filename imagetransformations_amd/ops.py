@@ -395,6 +395,39 @@ def add_noise(t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def add_noise_f64(t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """np.clip(img.astype(f32) + noise_f64, 0, 255).astype(u8) — cifar_image_transformations.py:45-47."""
+    t = _check_u8(t)
+    if noise.dtype != torch.float64 or noise.shape != t.shape or not noise.is_cuda:
+        raise ValueError("noise must be a float64 device tensor shaped like the image")
+    noise = noise.contiguous()
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_add_noise_f64_u8", F.vp(F.view_of(t)), F.vp(F.view_of(noise)), F.vp(F.view_of(out)), _stream())
+    return out
+
+
+def shot_noise_finish(counts: torch.Tensor, lam: float) -> torch.Tensor:
+    """np.clip(counts / lam * 255.0, 0, 255).astype(u8) for host-drawn Poisson counts (:68-69)."""
+    if counts.dtype != torch.float64 or not counts.is_cuda:
+        raise ValueError("counts must be a float64 device tensor")
+    counts = counts.contiguous()
+    out = torch.empty(counts.shape, dtype=torch.uint8, device=counts.device)
+    F.call("imgxf_shot_noise_u8", F.vp(F.view_of(counts)), float(lam), F.vp(F.view_of(out)), _stream())
+    return out
+
+
+def impulse_noise(t: torch.Tensor, mask: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
+    """img[mask < lo] = 0; img[mask > hi] = 255 for a host-drawn float64 mask [..,H,W] (:57-58)."""
+    t = _check_u8(t)
+    if mask.dtype != torch.float64 or not mask.is_cuda or tuple(mask.shape) != tuple(t.shape[:-1]):
+        raise ValueError("mask must be a float64 device tensor shaped like the image without channels")
+    mask = mask.contiguous().unsqueeze(-1)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_impulse_noise_u8", F.vp(F.view_of(t)), F.vp(F.view_of(mask)), float(lo), float(hi),
+           F.vp(F.view_of(out)), _stream())
+    return out
+
+
 def permute_channels(t: torch.Tensor, perm: Sequence[int]) -> torch.Tensor:
     """cv2.cvtColor channel shuffles: out[..., j] = t[..., perm[j]]."""
     t = _check_u8(t)

@@ -1,7 +1,7 @@
 """`TransformationPool` members that sit on the hot path, with the
 reference's static-method style and argument meaning
-(/root/reference/pipenline/cifar_image_transformations.py:37-129).  The remaining members
-(histogram equalisation, impulse / shot / float64 gaussian noise) are SURVEY §8f "next" rows and are not provided yet:
+(/root/reference/pipenline/cifar_image_transformations.py:37-129).  The remaining member
+(histogram_equalization: cv2 RGB<->YUV + equalizeHist, parity unpinnable here) is a SURVEY §8f "next" row and is not provided yet:
 asking for them raises AttributeError rather than silently running on the CPU."""
 from __future__ import annotations
 
@@ -10,11 +10,48 @@ import random
 import numpy as np
 from PIL import Image
 
+import torch
+
 from . import ops
-from .transformation import _download, _upload
+from .transformation import _device, _download, _upload
 
 
 class TransformationPool:
+    def gaussian_noise(image, severity=None):
+        """cifar_image_transformations.py:39-48.  Noise drawn on the host from np.random (same
+        stream as the reference for the same seed), added and clipped on the device in float64."""
+        if severity is None:
+            severity = random.choice([1, 2, 3, 4, 5])
+        img_array = np.array(image)
+        noise_std = [0.08, 0.12, 0.18, 0.26, 0.38][severity - 1]
+        noise = np.random.normal(0, noise_std * 255, img_array.shape)
+        dev = _device()
+        return _download(ops.add_noise_f64(torch.from_numpy(img_array).to(dev), torch.from_numpy(noise).to(dev)))
+
+    def impulse_noise(image, severity=None):
+        """cifar_image_transformations.py:50-59."""
+        if severity is None:
+            severity = random.choice([1, 2, 3, 4, 5])
+        img_array = np.array(image)
+        noise_prob = [0.03, 0.06, 0.09, 0.17, 0.27][severity - 1]
+        mask = np.random.random(img_array.shape[:2])
+        dev = _device()
+        out = ops.impulse_noise(torch.from_numpy(img_array).to(dev), torch.from_numpy(mask).to(dev),
+                                noise_prob / 2, 1 - noise_prob / 2)
+        return _download(out)
+
+    def shot_noise(image, severity=None):
+        """cifar_image_transformations.py:61-70.  The Poisson draw (whose rate is the float32
+        image scaled on the host, as in the reference) stays in NumPy; scaling back, clipping
+        and the uint8 cast run on the device."""
+        if severity is None:
+            severity = random.choice([1, 2, 3, 4, 5])
+        img_array = np.array(image).astype(np.float32)
+        lambda_val = [60, 25, 12, 5, 3][severity - 1]
+        scaled = img_array / 255.0 * lambda_val
+        counts = np.random.poisson(scaled).astype(np.float64)
+        return _download(ops.shot_noise_finish(torch.from_numpy(counts).to(_device()), lambda_val))
+
     def motion_blur(image, size=None):
         """cifar_image_transformations.py:109-119: cv2.filter2D with a horizontal 1/size row."""
         if size is None:

@@ -155,6 +155,17 @@ int imgxf_composite_u8(const imgxf_view* im1, const imgxf_view* im2, const imgxf
 int imgxf_filter3x3_u8(const imgxf_view* src, const imgxf_view* dst, const float* kernel9,
                        float scale, float offset, void* stream);
 
+/* ---- TransformationPool noise members, device half (cifar_image_transformations.py:39-70) ------
+ * The random draws stay on the host with NumPy's generator, exactly as the reference makes them;
+ * these apply them.  All float views are float64 (8-byte aligned).
+ * add_noise_f64:  dst = trunc(clip(f64(f32(p)) + noise, 0, 255))                   (:45-47)
+ * shot_noise:     dst = trunc(clip(counts / lambda * 255.0, 0, 255)), counts = Poisson draws (:68-69)
+ * impulse_noise:  mask [n,h,w,1]: mask < lo -> 0, mask > hi -> 255, else src      (:57-58) */
+int imgxf_add_noise_f64_u8(const imgxf_view* src, const imgxf_view* noise_f64, const imgxf_view* dst, void* stream);
+int imgxf_shot_noise_u8(const imgxf_view* counts_f64, double lambda, const imgxf_view* dst, void* stream);
+int imgxf_impulse_noise_u8(const imgxf_view* src, const imgxf_view* mask_f64, double lo, double hi,
+                           const imgxf_view* dst, void* stream);
+
 /* ---- ImageFilter.BoxBlur / ImageFilter.GaussianBlur — libImaging BoxBlur.c --------------------
  * (TransformationPool.defocus_blur, cifar_image_transformations.py:72-77.)  `passes` box passes
  * along x then along y, each in exact uint32 arithmetic with replicated edges and a uint8

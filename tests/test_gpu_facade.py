@@ -231,3 +231,34 @@ def test_pillow_gaussian_and_box_blur_bit_exact(device, hw):
                               np.asarray(img.filter(ImageFilter.GaussianBlur(radius=[3, 4, 6, 8, 10][sev - 1]))))
     gray = img.convert("L")
     assert np.array_equal(np.asarray(TransformationPool.defocus_blur(gray, 2)), np.asarray(gray.filter(ImageFilter.GaussianBlur(radius=4))))
+
+
+def test_pool_noise_members_follow_numpy_stream(device):
+    """gaussian / impulse / shot noise: same np.random stream as the reference for the same
+    seed, arithmetic after the draw on the device == the reference's NumPy expressions."""
+    from imagetransformations_amd.pool import TransformationPool
+    a = synth(10, 32, 32)
+    img = Image.fromarray(a)
+    for sev in (1, 3, 5):
+        np.random.seed(123)
+        got = np.asarray(TransformationPool.gaussian_noise(img, sev))
+        np.random.seed(123)
+        arr = a.astype(np.float32)
+        want = np.clip(arr + np.random.normal(0, [0.08, 0.12, 0.18, 0.26, 0.38][sev - 1] * 255, arr.shape), 0, 255).astype(np.uint8)
+        assert np.array_equal(got, want)
+        np.random.seed(124)
+        got = np.asarray(TransformationPool.impulse_noise(img, sev))
+        np.random.seed(124)
+        arr = a.astype(np.float32)
+        p = [0.03, 0.06, 0.09, 0.17, 0.27][sev - 1]
+        mask = np.random.random(arr.shape[:2])
+        arr[mask < p / 2] = 0
+        arr[mask > 1 - p / 2] = 255
+        assert np.array_equal(got, arr.astype(np.uint8))
+        np.random.seed(125)
+        got = np.asarray(TransformationPool.shot_noise(img, sev))
+        np.random.seed(125)
+        arr = a.astype(np.float32)
+        lam = [60, 25, 12, 5, 3][sev - 1]
+        noisy = np.random.poisson(arr / 255.0 * lam) / lam * 255.0
+        assert np.array_equal(got, np.clip(noisy, 0, 255).astype(np.uint8))
