@@ -19,6 +19,8 @@ struct AffineParams {
     int64_t q0, q3;  // m0, m3 in 2^-40 fixed point (per-pixel x increments of the BILINEAR fast path)
     int64_t q1, q4;  // m1, m4 likewise (per-row increments, LDS-staged path)
     int64_t x00, y00; // xin-.5, yin-.5 of output pixel (0,0) in 2^-40 fixed point (Pillow's fp64 value)
+    u32 ntx_magic;    // ceil(2^32 / ntx) of the LDS kernels' tile grid
+    int sx[4], sy[4]; // round(k*q0 / 2^16), round(k*q3 / 2^16): 8.24 steps to pixel k of a lane (LDS fast loop)
     u8 fill[4];
 };
 
@@ -403,6 +405,66 @@ __global__ __launch_bounds__(256) void affine_bilinear_kernel(View s, View d, Af
     }
 }
 
+// ---- stage the source bounding box of a tile into LDS (RGBX dword per pixel, row pitch PITCH):
+// wave w copies rows w, w+4, ...; lanes walk consecutive pixels of a source row (unaligned 4-byte
+// loads at a 3-byte lane stride: two cache lines per instruction).  All rows of a wave are in
+// flight at once (one memory latency per batch of NB rows); row pointers are scalar, the lane
+// contributes a 32-bit byte offset; rows past the box re-read its last row and are not written.
+// The frame's very last pixel cannot be read with a 4-byte load, so the one tile that owns it
+// reads that pixel from 1 byte earlier and shifts.
+template <int PITCH, int NB>
+__device__ __forceinline__ void stage_bbox(const View& s, const u8* sp, u32* srct, int lane, int wave,
+                                           int sx_lo, int sy_lo, int sx_hi, int sy_hi, int bwc, int bhc) {
+    const bool owns_last = sy_hi == s.h - 1 && sx_hi == s.w - 1;           // block-uniform
+    const int64_t gstep = 4 * s.rs;
+    for (int cc = lane; cc < bwc; cc += 64) {
+        u32* lp = srct + wave * PITCH + cc;
+        if (!owns_last) {
+            const u8* rowp = sp + (int64_t)(sy_lo + wave) * s.rs;           // scalar (wave-uniform)
+            const u32 loff = (u32)(sx_lo + cc) * 3u;
+            for (int r0 = wave; r0 < bhc; r0 += 4 * NB) {
+                u32 v[NB];
+                const int last = (bhc - 1 - r0) >> 2;                       // index of the wave's last row in this batch
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    v[i] = *(const u32_unaligned*)(rowp + (int64_t)min(i, last) * gstep + loff);
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    if (i <= last) lp[i * 4 * PITCH] = v[i];
+                rowp += NB * gstep;
+                lp += NB * 4 * PITCH;
+            }
+        } else {
+            const u8* gp = sp + (int64_t)(sy_lo + wave) * s.rs + (sx_lo + cc) * 3;
+            const u8* frame_last4 = sp + (int64_t)(s.h - 1) * s.rs + (int64_t)s.w * 3 - 4;
+            for (int rr = wave; rr < bhc; rr += 4) {
+                const bool tail = gp > frame_last4;
+                const u32 v = *(const u32_unaligned*)(tail ? gp - 1 : gp);
+                *lp = tail ? v >> 8 : v;
+                gp += gstep;
+                lp += 4 * PITCH;
+            }
+        }
+    }
+}
+
+#ifndef IMGXF_NEAREST_NB
+#define IMGXF_NEAREST_NB 13
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// byte B of a packed RGBX dword as float; asm so the compiler cannot turn (float)b - (float)a
+// into integer byte extraction + subtract + convert (3 extra VALU ops per tap pair)
+template <int B>
+__device__ __forceinline__ float ubyte_f(u32 w) {
+    float r;
+    if (B == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(w));
+    else if (B == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(w));
+    else if (B == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(w));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(w));
+    return r;
+}
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // ---------------------------------------------------------------------------------------
 // BILINEAR, LDS-staged source tile (RGB).  The three gather kernels above all cost ~79 cycles
 // per 64-lane load instruction on the texture-address path (PMC: every lane that touches a
@@ -413,7 +475,7 @@ __global__ __launch_bounds__(256) void affine_bilinear_kernel(View s, View d, Af
 // from LDS with one ds_read2_b32 per source row.  Coordinates, guard logic and the exact
 // fp64 hand-back are the same as in affine_bilinear_kernel.
 // ---------------------------------------------------------------------------------------
-template <bool PRECISE, int PITCH>
+template <bool PRECISE, int PITCH, bool DBG>
 __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d, AffineParams P, View dbg,
                                                                   int ntx, int nty) {
     constexpr int C = 3, TXG = 8, WX = 1, TR = 8, BW = 32, BH = 32;   // square tile: smallest rotated bbox
@@ -427,8 +489,9 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
     const int orig = blockIdx.x, xcd = orig & 7, q = nblocks >> 3, r = nblocks & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     const int f = blockIdx.y;
-    const int tyb = logical / ntx, txb = logical - tyb * ntx;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // logical / ntx by the host's reciprocal (exact: logical * ntx < 2^32) keeps the tile setup scalar
+    const int tyb = P.ntx_magic ? (int)__umulhi((u32)logical, P.ntx_magic) : logical, txb = logical - tyb * ntx;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lx = ((wave % WX) * TXG + (lane % TXG)) * 4, ly = (wave / WX) * TR + lane / TXG;
     const int x0 = txb * BW + lx, y = tyb * BH + ly;
     const int wx0 = txb * BW + (wave % WX) * TXG * 4, wy0 = tyb * BH + (wave / WX) * TR;
@@ -455,29 +518,7 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
     // of a source row (unaligned 4-byte loads at a 3-byte lane stride: two cache lines per
     // instruction).  The frame's very last pixel cannot be read with a 4-byte load, so the one
     // tile that owns it reads that pixel from 1 byte earlier and shifts.
-    const bool owns_last = sy_hi == s.h - 1 && sx_hi == s.w - 1;           // block-uniform
-    for (int cc = lane; cc < bwc; cc += 64) {
-        const u8* gp = sp + (int64_t)(sy_lo + wave) * s.rs + (sx_lo + cc) * 3;
-        u32* lp = srct + wave * PITCH + cc;
-        const int64_t gstep = 4 * s.rs;
-        if (!owns_last) {
-#pragma unroll 4
-            for (int rr = wave; rr < bhc; rr += 4) {
-                *lp = *(const u32_unaligned*)gp;
-                gp += gstep;
-                lp += 4 * PITCH;
-            }
-        } else {
-            const u8* frame_last4 = sp + (int64_t)(s.h - 1) * s.rs + (int64_t)s.w * 3 - 4;
-            for (int rr = wave; rr < bhc; rr += 4) {
-                const bool tail = gp > frame_last4;
-                const u32 v = *(const u32_unaligned*)(tail ? gp - 1 : gp);
-                *lp = tail ? v >> 8 : v;
-                gp += gstep;
-                lp += 4 * PITCH;
-            }
-        }
-    }
+    stage_bbox<PITCH, 9>(s, sp, srct, lane, wave, sx_lo, sy_lo, sx_hi, sy_hi, bwc, bhc);
     __syncthreads();
 
     auto exact_pixel = [&](int x, u8 (&px)[C], float (&vv)[C]) {
@@ -514,6 +555,119 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
     const int64_t XL = XT + lx * P.q0 + ly * P.q1 - ((int64_t)ux_lo << 40);
     const int64_t YL = YT + lx * P.q3 + ly * P.q4 - ((int64_t)uy_lo << 40);
     const int offx = ux_lo - sx_lo, offy = uy_lo - sy_lo;          // <= 0 where the bbox was clipped
+
+    // ---- interior tiles (block-uniform): the tile lies inside the output and the 2x2 support of
+    // every pixel inside the source, so there is no bounds test and no fill.  Straight-line code
+    // for the lane's 4 pixels (the compiler interleaves their LDS reads); pixel k's coordinate is
+    // pixel 0's rounded 8.24 value plus the host-rounded step sx[k] (|error| <= 2^-24 px in total,
+    // so |fp32 - fp64| <= 2*255*6e-8 + 3*7.6e-6 = 5.3e-5 < GUARD).  Pixels that need libImaging's
+    // fp64 sequence are collected in a lane mask and handled after the loop.
+    const bool clean = ux_lo >= 0 && uy_lo >= 0 && (int)(xhi >> 40) + 1 <= s.w - 1 && (int)(yhi >> 40) + 1 <= s.h - 1 &&
+                       txb * BW + BW <= d.w && tyb * BH + BH <= d.h;
+    if (clean) {
+        const int Xb = (int)((XL + 32768) >> 16), Yb = (int)((YL + 32768) >> 16);   // rounded: |error| <= 2^-25
+        u32 od[C] = {0u, 0u, 0u};
+        u32 need = 0;                                    // bit k: redo pixel k; bit 4+k: its support is unsure
+        float vf[DBG ? 4 : 1][C];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int X32 = Xb + P.sx[k], Y32 = Yb + P.sy[k];
+            const u32 fx = (u32)X32 & (FONE - 1), fy = (u32)Y32 & (FONE - 1);
+            const u32 hx = (fx & (FHALF - 1)) - CG32, hy = (fy & (FHALF - 1)) - CG32;
+            const bool unsure = max(hx, hy) >= (u32)(FHALF - 2 * CG32);
+            const f32x2 dd = f32x2{(float)fx, (float)fy} * f32x2{5.9604644775390625e-08f, 5.9604644775390625e-08f};   // 2^-24
+            const float dxf = dd.x, dyf = dd.y;
+            const int li = (Y32 >> 24) * PITCH + (X32 >> 24);
+            const u32 p00 = srct[li], p01 = srct[li + 1], p10 = srct[li + PITCH], p11 = srct[li + PITCH + 1];
+            const f32x2 dx2 = {dxf, dxf}, dy2 = {dyf, dyf};
+            // R,G as a pair through both lerps; B's two rows as a pair through the first lerp
+            const f32x2 a = {ubyte_f<0>(p00), ubyte_f<1>(p00)}, b = {ubyte_f<0>(p01), ubyte_f<1>(p01)};
+            const f32x2 c = {ubyte_f<0>(p10), ubyte_f<1>(p10)}, e = {ubyte_f<0>(p11), ubyte_f<1>(p11)};
+            const f32x2 v1 = fma2(b - a, dx2, a), v2 = fma2(e - c, dx2, c);
+            const f32x2 vrg = fma2(v2 - v1, dy2, v1);
+            const f32x2 ab = {ubyte_f<2>(p00), ubyte_f<2>(p10)}, bb = {ubyte_f<2>(p01), ubyte_f<2>(p11)};
+            const f32x2 vb12 = fma2(bb - ab, dx2, ab);
+            const float vb = fmaf(vb12.y - vb12.x, dyf, vb12.x);
+            // v >= 0: (UINT8)v == floor(v); |frac(v) - .5| close to .5 <=> v close to an integer
+            const f32x2 flrg = {floorf(vrg.x), floorf(vrg.y)};
+            const float flb = floorf(vb);
+            od[(k * C + 0) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(flrg.x, (k * C + 0) & 3, od[(k * C + 0) >> 2]);
+            od[(k * C + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(flrg.y, (k * C + 1) & 3, od[(k * C + 1) >> 2]);
+            od[(k * C + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(flb, (k * C + 2) & 3, od[(k * C + 2) >> 2]);
+            float dist = 0.0f;
+            if (PRECISE) {
+                const f32x2 urg = (vrg - flrg) - f32x2{0.5f, 0.5f};
+                const float ub = (vb - flb) - 0.5f;
+                dist = fmaxf(fmaxf(fabsf(urg.x), fabsf(urg.y)), fabsf(ub));
+            }
+            if (DBG) { vf[k][0] = vrg.x; vf[k][1] = vrg.y; vf[k][2] = vb; }
+            const bool near_int = PRECISE && dist > 0.5f - GUARD;
+            need |= (unsure ? 0x11u << k : 0u) | (near_int ? 1u << k : 0u);
+        }
+        if (need) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((need >> k) & 1u) {
+                    u8 px[C]; float vv[C];
+                    bool have = true;
+                    if ((need >> (4 + k)) & 1u) {
+                        exact_pixel(x0 + k, px, vv);
+                    } else {
+                        // the support is certain: only dx, dy and the lerps need libImaging's fp64
+                        // sequence, on the taps re-read from LDS.  A flat support is exact in fp32.
+                        const int X32 = Xb + P.sx[k], Y32 = Yb + P.sy[k];
+                        const int li = (Y32 >> 24) * PITCH + (X32 >> 24);
+                        const u32 p00 = srct[li], p01 = srct[li + 1], p10 = srct[li + PITCH], p11 = srct[li + PITCH + 1];
+                        have = (((p00 ^ p01) | (p10 ^ p11) | (p00 ^ p10)) << 8) != 0;
+                        if (have) {
+                            const double xc = (double)(x0 + k) + 0.5, yc = (double)y + 0.5;
+                            const double xin = ((P.m[0] * xc + P.m[1] * yc) + P.m[2]) - 0.5;
+                            const double yin = ((P.m[3] * xc + P.m[4] * yc) + P.m[5]) - 0.5;
+                            const double dxd = xin - floor(xin), dyd = yin - floor(yin);
+#pragma unroll
+                            for (int j = 0; j < C; ++j) {
+                                const double ta = (double)((p00 >> (8 * j)) & 0xffu), tb = (double)((p01 >> (8 * j)) & 0xffu);
+                                const double tc = (double)((p10 >> (8 * j)) & 0xffu), te = (double)((p11 >> (8 * j)) & 0xffu);
+                                const double w1 = ta + (tb - ta) * dxd, w2 = tc + (te - tc) * dxd;
+                                const double w = w1 + (w2 - w1) * dyd;
+                                vv[j] = (float)w; px[j] = (u8)(int)w;
+                            }
+                        }
+                    }
+                    if (have) {
+#pragma unroll
+                        for (int j = 0; j < C; ++j) {
+                            const int q = (k * C + j) >> 2, sh = ((k * C + j) & 3) * 8;
+                            od[q] = (od[q] & ~(0xffu << sh)) | ((u32)px[j] << sh);
+                            if (DBG) vf[k][j] = vv[j];
+                        }
+                    }
+                }
+            }
+        }
+        if (DBG) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float* fp = (float*)dbg.row(f, y) + (x0 + k) * C;
+#pragma unroll
+                for (int j = 0; j < C; ++j) fp[j] = vf[k][j];
+            }
+        }
+        if (staged) {
+            u8* seg = d.row(f, y) + (x0 - (lane % TXG) * 4) * C;
+            staged_store<C, TXG>(stage[wave], od, lane, seg);
+        } else {
+            u8* dp = d.row(f, y) + x0 * C;
+            if ((((uintptr_t)dp) & 3) == 0) {
+#pragma unroll
+                for (int qq = 0; qq < C; ++qq) ((u32*)dp)[qq] = od[qq];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4 * C; ++e) dp[e] = (u8)(od[e >> 2] >> ((e & 3) * 8));
+            }
+        }
+        return;
+    }
     u8 out[4 * C];
     float vf[4][C];
 #pragma unroll
@@ -623,8 +777,9 @@ __global__ __launch_bounds__(256) void affine_nearest_lds_kernel(View s, View d,
     const int orig = blockIdx.x, xcd = orig & 7, q = nblocks >> 3, r = nblocks & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     const int f = blockIdx.y;
-    const int tyb = logical / ntx, txb = logical - tyb * ntx;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // logical / ntx by the host's reciprocal (exact: logical * ntx < 2^32) keeps the tile setup scalar
+    const int tyb = P.ntx_magic ? (int)__umulhi((u32)logical, P.ntx_magic) : logical, txb = logical - tyb * ntx;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lx = ((wave % WX) * TXG + (lane % TXG)) * 4, ly = (wave / WX) * TR + lane / TXG;
     const int x0 = txb * BW + lx, y = tyb * BH + ly;
     const int wx0 = txb * BW + (wave % WX) * TXG * 4, wy0 = tyb * BH + (wave / WX) * TR;
@@ -642,24 +797,7 @@ __global__ __launch_bounds__(256) void affine_nearest_lds_kernel(View s, View d,
     const int sy_lo = max((YT + min(ay, 0) + min(by, 0)) >> 16, 0), sy_hi = min((YT + max(ay, 0) + max(by, 0)) >> 16, s.h - 1);
     const int bwc = sx_hi - sx_lo + 1, bhc = sy_hi - sy_lo + 1;
 
-    const bool owns_last = sy_hi == s.h - 1 && sx_hi == s.w - 1;
-    for (int cc = lane; cc < bwc; cc += 64) {
-        const u8* gp = sp + (int64_t)(sy_lo + wave) * s.rs + (sx_lo + cc) * 3;
-        u32* lp = srct + wave * PITCH + cc;
-        const int64_t gstep = 4 * s.rs;
-        if (!owns_last) {
-#pragma unroll 4
-            for (int rr = wave; rr < bhc; rr += 4) { *lp = *(const u32_unaligned*)gp; gp += gstep; lp += 4 * PITCH; }
-        } else {
-            const u8* frame_last4 = sp + (int64_t)(s.h - 1) * s.rs + (int64_t)s.w * 3 - 4;
-            for (int rr = wave; rr < bhc; rr += 4) {
-                const bool tail = gp > frame_last4;
-                const u32 v = *(const u32_unaligned*)(tail ? gp - 1 : gp);
-                *lp = tail ? v >> 8 : v;
-                gp += gstep; lp += 4 * PITCH;
-            }
-        }
-    }
+    stage_bbox<PITCH, IMGXF_NEAREST_NB>(s, sp, srct, lane, wave, sx_lo, sy_lo, sx_hi, sy_hi, bwc, bhc);
     __syncthreads();
 
     const u32 fillw = (u32)P.fill[0] | ((u32)P.fill[1] << 8) | ((u32)P.fill[2] << 16);
@@ -762,6 +900,7 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
         const int ntx = (d.w + 31) / 32, nty = (d.h + 31) / 32;
         if (nowrap && bw <= 97 && bh <= 100 && (int64_t)ntx * nty < 0x7fffffff && d.n <= 65535) {
             dim3 grid((unsigned)(ntx * nty), (unsigned)d.n);
+            P.ntx_magic = (u32)((((uint64_t)1 << 32) + ntx - 1) / ntx);   // ntx, nty <= 1024: exact; 0 when ntx == 1
             if (bw <= 49) hipLaunchKernelGGL((affine_nearest_lds_kernel<49>), grid, dim3(256), (size_t)49 * bh * 4 + 16, st, s, d, P, ntx, nty);
             else if (bw <= 65) hipLaunchKernelGGL((affine_nearest_lds_kernel<65>), grid, dim3(256), (size_t)65 * bh * 4 + 16, st, s, d, P, ntx, nty);
             else hipLaunchKernelGGL((affine_nearest_lds_kernel<97>), grid, dim3(256), (size_t)97 * bh * 4 + 16, st, s, d, P, ntx, nty);
@@ -781,6 +920,10 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
     fixed_ok = fixed_ok && fabs(m[1]) < 64.0 && fabs(m[4]) < 64.0;
     P.q1 = fixed_ok ? llround(m[1] * 1099511627776.0) : 0;
     P.q4 = fixed_ok ? llround(m[4] * 1099511627776.0) : 0;
+    for (int k = 0; k < 4; ++k) {
+        P.sx[k] = (int)((k * P.q0 + (k * P.q0 >= 0 ? 32768 : -32768)) / 65536);   // round to nearest 2^-24
+        P.sy[k] = (int)((k * P.q3 + (k * P.q3 >= 0 ? 32768 : -32768)) / 65536);
+    }
     if (fixed_ok) {
         const double x0d = (m[0] * 0.5 + m[1] * 0.5) + m[2] - 0.5, y0d = (m[3] * 0.5 + m[4] * 0.5) + m[5] - 0.5;
         P.x00 = (int64_t)floor(x0d * 1099511627776.0);
@@ -797,11 +940,17 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
             const int ntx = (d.w + 31) / 32, nty = (d.h + 31) / 32;
             if (bw <= 97 && bh <= 100 && (int64_t)ntx * nty < 0x7fffffff && d.n <= 65535) {
                 dim3 grid((unsigned)(ntx * nty), (unsigned)d.n);
+                P.ntx_magic = (u32)((((uint64_t)1 << 32) + ntx - 1) / ntx);   // ntx, nty <= 1024: exact; 0 when ntx == 1
 #define IMGXF_LDS(PITCH)                                                                           \
     do {                                                                                           \
         const size_t lds = (size_t)PITCH * bh * 4 + 16;                                            \
-        if (pr) hipLaunchKernelGGL((affine_bilinear_lds_kernel<true, PITCH>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty); \
-        else hipLaunchKernelGGL((affine_bilinear_lds_kernel<false, PITCH>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty);  \
+        if (dbg.p) {                                                                               \
+            if (pr) hipLaunchKernelGGL((affine_bilinear_lds_kernel<true, PITCH, true>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty); \
+            else hipLaunchKernelGGL((affine_bilinear_lds_kernel<false, PITCH, true>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty); \
+        } else {                                                                                   \
+            if (pr) hipLaunchKernelGGL((affine_bilinear_lds_kernel<true, PITCH, false>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty); \
+            else hipLaunchKernelGGL((affine_bilinear_lds_kernel<false, PITCH, false>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty); \
+        }                                                                                          \
         return launch_status();                                                                    \
     } while (0)
                 if (bw <= 49) IMGXF_LDS(49);
