@@ -831,6 +831,100 @@ __global__ __launch_bounds__(256) void affine_nearest_lds_kernel(View s, View d,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// NEAREST with LDS-DMA staging (16-byte aligned sources).  The kernel above is bound by the L1
+// address path: its staging loads are dwords at a 3-byte lane stride and cost ~16 TCP accesses
+// per wave-level load for 192 useful bytes.  Here the bounding box is fetched as packed RGB rows
+// in 16-byte chunks straight into LDS (global_load_lds_dwordx4: 1 KiB per wave-level load, no
+// VGPR round trip): lane i of the workgroup's DMA round j owns chunk idx = 256 j + i of the
+// [row][DCH] chunk grid, whose LDS image is simply idx * 16.  The gather then reads the two
+// aligned dwords around byte 3*x of the packed row and funnel-shifts.
+// Preconditions (host): src data / row stride / frame stride / row bytes all multiples of 16,
+// bbox <= 49 pixels wide (<= DCH chunks whatever its alignment) and <= 52 rows.
+// ---------------------------------------------------------------------------------------
+#define IMGXF_AFF_GLDS16(gptr, lptr)                                                           \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),    \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+constexpr int DCH = 11, DPITCH = DCH * 16;      // chunks and bytes per staged row
+
+__global__ __launch_bounds__(256) void affine_nearest_dma_kernel(View s, View d, AffineParams P, int ntx, int nty) {
+    constexpr int C = 3, TXG = 8, WX = 1, TR = 8, BW = 32, BH = 32;
+    extern __shared__ __attribute__((aligned(16))) char srcb[];      // bhc x DPITCH bytes (+16)
+    __shared__ __attribute__((aligned(16))) u32 stage[4][64 * C + 2 * (64 / TXG) + 4];
+    const int nblocks = ntx * nty;
+    const int orig = blockIdx.x, xcd = orig & 7, q = nblocks >> 3, r = nblocks & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int f = blockIdx.y;
+    const int tyb = P.ntx_magic ? (int)__umulhi((u32)logical, P.ntx_magic) : logical, txb = logical - tyb * ntx;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lx = ((wave % WX) * TXG + (lane % TXG)) * 4, ly = (wave / WX) * TR + lane / TXG;
+    const int x0 = txb * BW + lx, y = tyb * BH + ly;
+    const int wx0 = txb * BW + (wave % WX) * TXG * 4, wy0 = tyb * BH + (wave / WX) * TR;
+    const bool staged = wx0 + TXG * 4 <= d.w && wy0 + TR <= d.h &&
+                        ((((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs | (uintptr_t)(wx0 * C)) & 15) == 0;
+    const bool valid = y < d.h && x0 < d.w;
+    const u8* sp = s.p + (int64_t)f * s.fs;
+
+    const int XT = P.fx[2] + P.fx[1] * (tyb * BH) + P.fx[0] * (txb * BW);
+    const int YT = P.fx[5] + P.fx[4] * (tyb * BH) + P.fx[3] * (txb * BW);
+    const int ax = (BW - 1) * P.fx[0], bx = (BH - 1) * P.fx[1], ay = (BW - 1) * P.fx[3], by = (BH - 1) * P.fx[4];
+    const int sx_lo = max((XT + min(ax, 0) + min(bx, 0)) >> 16, 0), sx_hi = min((XT + max(ax, 0) + max(bx, 0)) >> 16, s.w - 1);
+    const int sy_lo = max((YT + min(ay, 0) + min(by, 0)) >> 16, 0), sy_hi = min((YT + max(ay, 0) + max(by, 0)) >> 16, s.h - 1);
+    const int bwc = sx_hi - sx_lo + 1, bhc = sy_hi - sy_lo + 1;
+    const int a0 = (sx_lo * 3) & ~15;                  // first staged byte of every row
+    const int last_chunk = s.w * 3 - 16;               // chunks past the row end re-read its last one
+
+    if (bwc > 0 && bhc > 0) {
+        const int nchunks = bhc * DCH;                 // <= 52 * 11
+        const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)srcb;
+        (void)lds0;
+        for (int base = wave * 64; base < nchunks; base += 256) {          // wave-uniform trip count
+            const int idx = base + lane;
+            if (idx < nchunks) {
+                const int row = (int)(((u32)idx * 5958u) >> 16);            // idx / 11 for idx < 2^13
+                const int ch = idx - row * DCH;
+                const u8* gp = sp + (int64_t)(sy_lo + row) * s.rs + min(a0 + ch * 16, last_chunk);
+                IMGXF_AFF_GLDS16(gp, srcb + base * 16);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const u32 fillw = (u32)P.fill[0] | ((u32)P.fill[1] << 8) | ((u32)P.fill[2] << 16);
+    const int XL = XT + lx * P.fx[0] + ly * P.fx[1], YL = YT + lx * P.fx[3] + ly * P.fx[4];
+    u32 px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xi = ((XL + k * P.fx[0]) >> 16) - sx_lo, yi = ((YL + k * P.fx[3]) >> 16) - sy_lo;
+        const bool in = bwc > 0 && bhc > 0 && (u32)xi < (u32)bwc && (u32)yi < (u32)bhc;
+        const int bo = in ? (int)__umul24((u32)yi, (u32)DPITCH) + (xi + sx_lo) * 3 - a0 : 0;
+        const u32* wp = (const u32*)(srcb + (bo & ~3));
+        const u32 lo = wp[0], hi = wp[1];
+        const u32 t = __builtin_amdgcn_alignbyte(hi, lo, (u32)bo & 3u);
+        px[k] = in ? (t & 0xffffffu) : fillw;
+    }
+    u32 od[3];
+    od[0] = px[0] | (px[1] << 24);
+    od[1] = (px[1] >> 8) | (px[2] << 16);
+    od[2] = (px[2] >> 16) | (px[3] << 8);
+    if (staged) {
+        u8* seg = d.row(f, y) + (x0 - (lane % TXG) * 4) * C;
+        staged_store<C, TXG>(stage[wave], od, lane, seg);
+        return;
+    }
+    if (!valid) return;
+    u8* dp = d.row(f, y) + x0 * C;
+    const int npx = min(4, d.w - x0);
+    if (npx == 4 && ((((uintptr_t)dp) & 3) == 0)) {
+#pragma unroll
+        for (int qq = 0; qq < C; ++qq) ((u32*)dp)[qq] = od[qq];
+    } else {
+        for (int e = 0; e < npx * C; ++e) dp[e] = (u8)(px[e / 3] >> (8 * (e % 3)));
+    }
+}
+
 static inline int fix16(double v) {
     const double t = v * 65536.0 + 0.5;
     return t < 0.0 ? (int)floor(t) : (int)t;   // libImaging FLOOR()
@@ -901,6 +995,12 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
         if (nowrap && bw <= 97 && bh <= 100 && (int64_t)ntx * nty < 0x7fffffff && d.n <= 65535) {
             dim3 grid((unsigned)(ntx * nty), (unsigned)d.n);
             P.ntx_magic = (u32)((((uint64_t)1 << 32) + ntx - 1) / ntx);   // ntx, nty <= 1024: exact; 0 when ntx == 1
+            static const bool no_dma = getenv("IMGXF_AFFINE_NO_DMA") != nullptr;
+            if (bw <= 49 && bh <= 52 && !no_dma && src->w * 3 >= 16 && (src->w * 3) % 16 == 0 &&
+                ((((uintptr_t)src->data) | (uintptr_t)src->row_stride | (uintptr_t)src->frame_stride) & 15) == 0) {
+                hipLaunchKernelGGL(affine_nearest_dma_kernel, grid, dim3(256), (size_t)DPITCH * bh + 32, st, s, d, P, ntx, nty);
+                return launch_status();
+            }
             if (bw <= 49) hipLaunchKernelGGL((affine_nearest_lds_kernel<49>), grid, dim3(256), (size_t)49 * bh * 4 + 16, st, s, d, P, ntx, nty);
             else if (bw <= 65) hipLaunchKernelGGL((affine_nearest_lds_kernel<65>), grid, dim3(256), (size_t)65 * bh * 4 + 16, st, s, d, P, ntx, nty);
             else hipLaunchKernelGGL((affine_nearest_lds_kernel<97>), grid, dim3(256), (size_t)97 * bh * 4 + 16, st, s, d, P, ntx, nty);
