@@ -62,6 +62,9 @@ SIGNATURES = {
     "imgxf_add_noise_f64_u8": [_VP, _VP, _VP, C.c_void_p],
     "imgxf_shot_noise_u8": [_VP, C.c_double, _VP, C.c_void_p],
     "imgxf_impulse_noise_u8": [_VP, _VP, C.c_double, C.c_double, _VP, C.c_void_p],
+    "imgxf_lut_u8": [_VP, _VP, _U8, C.c_void_p],
+    "imgxf_equalize_u8": [_VP, _VP, C.c_void_p, C.c_size_t, C.c_void_p],
+    "imgxf_channel_histogram_u8": [_VP, C.c_void_p, C.c_void_p],
     "imgxf_box_blur_u8": [_VP, _VP, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p],
     "imgxf_gaussian_blur_pil_u8": [_VP, _VP, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p],
     "imgxf_filter3x3_u8": [_VP, _VP, _F, C.c_float, C.c_float, C.c_void_p],

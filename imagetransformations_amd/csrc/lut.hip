@@ -1,0 +1,170 @@
+// Lookup-table point ops of the AugMix operation set (/root/reference/fall_2025/AugMix.py:31,36,37:
+// ImageOps.posterize / equalize / solarize) and the per-channel histogram behind
+// ImageOps.equalize and the Shannon-entropy feature
+// (/root/reference/fall_2025/Initial_Experiments.py:95-113).  All integer, bit-exact.
+//   chist_kernel        [n][c][256] uint32 histogram, LDS-privatised per workgroup
+//   equalize_lut_kernel ImageOps.equalize's table from one channel histogram (one lane per table)
+//   lut_apply_kernel    dst = lut[frame][channel][src]; tables staged in LDS, 16 bytes per lane
+#include "imgxf_common.h"
+#include <string.h>
+
+namespace imgxf {
+
+__global__ __launch_bounds__(256) void chist_kernel(View s, u32* hist) {
+    __shared__ u32 h[4 * 256];
+    const int C = s.c;
+    for (int i = threadIdx.x; i < C * 256; i += 256) h[i] = 0;
+    __syncthreads();
+    const int f = blockIdx.y;
+    const int rowbytes = s.w * C;
+    const int64_t total = (int64_t)s.h * rowbytes;
+    const bool vec = (rowbytes % 4 == 0) && ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 3) == 0;
+    if (vec) {
+        const int rowwords = rowbytes >> 2;
+        const int64_t words = (int64_t)s.h * rowwords;
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < words; t += (int64_t)gridDim.x * 256) {
+            const int xw = (int)(t % rowwords), y = (int)(t / rowwords);
+            const u32 v = ((const u32*)s.row(f, y))[xw];
+            int ch = (xw * 4) % C;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                atomicAdd(&h[ch * 256 + ((v >> (8 * b)) & 0xffu)], 1u);
+                ch = ch + 1 == C ? 0 : ch + 1;
+            }
+        }
+    } else {
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+            const int xb = (int)(t % rowbytes), y = (int)(t / rowbytes);
+            atomicAdd(&h[(xb % C) * 256 + s.row(f, y)[xb]], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 256; i += 256)
+        if (h[i]) atomicAdd(&hist[(int64_t)f * C * 256 + i], h[i]);
+}
+
+// PIL/ImageOps.py equalize(): histo = non-zero bins; step = (sum(histo) - histo[-1]) // 255;
+// identity when there is at most one non-zero bin or step == 0; else n = step // 2 and
+// lut[i] = n // step, n += h[i].  image.point() clips table entries to 0..255 (getlist/CLIP8).
+__global__ void equalize_lut_kernel(const u32* hist, u8* lut, int ntables) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntables) return;
+    const u32* h = hist + (int64_t)t * 256;
+    u8* l = lut + (int64_t)t * 256;
+    unsigned long long sum = 0;
+    u32 lastnz = 0;
+    int nnz = 0;
+    for (int i = 0; i < 256; ++i) {
+        sum += h[i];
+        if (h[i]) { lastnz = h[i]; ++nnz; }
+    }
+    const unsigned long long step = nnz <= 1 ? 0 : (sum - lastnz) / 255;
+    if (step == 0) {
+        for (int i = 0; i < 256; ++i) l[i] = (u8)i;
+        return;
+    }
+    unsigned long long n = step / 2;
+    for (int i = 0; i < 256; ++i) {
+        const unsigned long long v = n / step;
+        l[i] = v > 255 ? (u8)255 : (u8)v;
+        n += h[i];
+    }
+}
+
+struct LutArg { u8 t[4 * 256]; };
+
+// lut: device tables [n][c][256] (per-frame) when `dev` is set, else the by-value table for all frames
+__global__ __launch_bounds__(256) void lut_apply_kernel(View s, View d, const u8* dev, LutArg arg) {
+    __shared__ __attribute__((aligned(16))) u8 tab[4 * 256];
+    const int C = d.c;
+    const int f = blockIdx.y;
+    for (int i = threadIdx.x; i < C * 256; i += 256) tab[i] = dev ? dev[(int64_t)f * C * 256 + i] : arg.t[i];
+    __syncthreads();
+    const int rowbytes = d.w * C;
+    const bool vec = (rowbytes % 4 == 0) &&
+                     ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | (uintptr_t)d.p | (uintptr_t)d.rs | (uintptr_t)d.fs) & 3) == 0;
+    if (vec) {
+        const int rowwords = rowbytes >> 2;
+        const int64_t words = (int64_t)d.h * rowwords;
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < words; t += (int64_t)gridDim.x * 256) {
+            const int xw = (int)(t % rowwords), y = (int)(t / rowwords);
+            const u32 v = ((const u32*)s.row(f, y))[xw];
+            int ch = (xw * 4) % C;
+            u32 o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                o |= (u32)tab[ch * 256 + ((v >> (8 * b)) & 0xffu)] << (8 * b);
+                ch = ch + 1 == C ? 0 : ch + 1;
+            }
+            ((u32*)d.row(f, y))[xw] = o;
+        }
+    } else {
+        const int64_t total = (int64_t)d.h * rowbytes;
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+            const int xb = (int)(t % rowbytes), y = (int)(t / rowbytes);
+            d.row(f, y)[xb] = tab[(xb % C) * 256 + s.row(f, y)[xb]];
+        }
+    }
+}
+
+static inline unsigned blocks_for(int64_t items) {
+    int64_t b = (items + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+} // namespace imgxf
+
+using namespace imgxf;
+
+IMGXF_API int imgxf_channel_histogram_u8(const imgxf_view* src, uint32_t* hist, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    if (!hist) return IMGXF_ERR_NULL;
+    if (src->n == 0) return IMGXF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)src->n * src->c * 256 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return (int)e;
+    if (empty_view(src)) return IMGXF_OK;
+    const View s = make_view(src);
+    if (s.n > 65535) return IMGXF_ERR_SHAPE;
+    hipLaunchKernelGGL(chist_kernel, dim3(blocks_for((int64_t)s.h * s.rowbytes() / 16), (unsigned)s.n), dim3(256), 0, st, s, hist);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_lut_u8(const imgxf_view* src, const imgxf_view* dst, const uint8_t* lut, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    if (!lut) return IMGXF_ERR_NULL;
+    if (!same_geometry(src, dst)) return IMGXF_ERR_SHAPE;
+    if (empty_view(dst)) return IMGXF_OK;
+    const View s = make_view(src), d = make_view(dst);
+    if (d.n > 65535) return IMGXF_ERR_SHAPE;
+    LutArg arg;
+    memset(&arg, 0, sizeof(arg));
+    memcpy(arg.t, lut, (size_t)d.c * 256);
+    hipLaunchKernelGGL(lut_apply_kernel, dim3(blocks_for((int64_t)d.h * d.rowbytes() / 16), (unsigned)d.n), dim3(256), 0,
+                       (hipStream_t)stream, s, d, (const u8*)nullptr, arg);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_equalize_u8(const imgxf_view* src, const imgxf_view* dst, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    if (!same_geometry(src, dst)) return IMGXF_ERR_SHAPE;
+    if (empty_view(dst)) return IMGXF_OK;
+    const View s = make_view(src), d = make_view(dst);
+    if (d.n > 65535) return IMGXF_ERR_SHAPE;
+    const size_t ntab = (size_t)d.n * d.c;
+    if (!workspace) return IMGXF_ERR_NULL;
+    if (workspace_bytes < ntab * 256 * 5 || (((uintptr_t)workspace) & 3)) return IMGXF_ERR_WORKSPACE;
+    u32* hist = (u32*)workspace;
+    u8* lut = (u8*)workspace + ntab * 256 * 4;
+    IMGXF_CHECK(imgxf_channel_histogram_u8(src, hist, stream));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(equalize_lut_kernel, dim3((unsigned)((ntab + 63) / 64)), dim3(64), 0, st, hist, lut, (int)ntab);
+    LutArg arg;
+    memset(&arg, 0, sizeof(arg));
+    hipLaunchKernelGGL(lut_apply_kernel, dim3(blocks_for((int64_t)d.h * d.rowbytes() / 16), (unsigned)d.n), dim3(256), 0, st,
+                       s, d, (const u8*)lut, arg);
+    return launch_status();
+}

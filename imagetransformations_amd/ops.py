@@ -428,6 +428,70 @@ def impulse_noise(t: torch.Tensor, mask: torch.Tensor, lo: float, hi: float) -> 
     return out
 
 
+def lut(t: torch.Tensor, table) -> torch.Tensor:
+    """Image.point(table): `table` is 256 entries (all channels) or c*256 (per channel), host side."""
+    t = _check_u8(t)
+    c = _hwc(t)[2]
+    tab = [int(v) & 0xFF for v in table]
+    if len(tab) == 256:
+        tab = tab * c
+    if len(tab) != 256 * c:
+        raise ValueError(f"lookup table needs 256 or {256 * c} entries, got {len(tab)}")
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_lut_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.u8_array(tab, len(tab)), _stream())
+    return out
+
+
+def posterize(t: torch.Tensor, bits: int) -> torch.Tensor:
+    """ImageOps.posterize (fall_2025/AugMix.py:31)."""
+    mask = ~(2 ** (8 - int(bits)) - 1)
+    return lut(t, [i & mask for i in range(256)])
+
+
+def solarize(t: torch.Tensor, threshold: int = 128) -> torch.Tensor:
+    """ImageOps.solarize (fall_2025/AugMix.py:37)."""
+    return lut(t, [i if i < threshold else 255 - i for i in range(256)])
+
+
+def equalize(t: torch.Tensor) -> torch.Tensor:
+    """ImageOps.equalize per frame and channel (fall_2025/AugMix.py:36); histogram, table and
+    mapping all run on the device."""
+    t = _check_u8(t)
+    h, w, c = _hwc(t)
+    n = t.shape[0] if t.dim() == 4 else 1
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    ws = torch.empty(max(1, n * c * 256 * 5 // 4 + 1), dtype=torch.int32, device=t.device)
+    F.call("imgxf_equalize_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), ws.data_ptr(), ws.numel() * 4, _stream())
+    return out
+
+
+def channel_histogram(t: torch.Tensor) -> torch.Tensor:
+    """[N, C, 256] int32 histogram of a [N,H,W,C] / [H,W,C] / [H,W] uint8 tensor."""
+    t = _check_u8(t)
+    h, w, c = _hwc(t)
+    n = t.shape[0] if t.dim() == 4 else 1
+    hist = torch.empty((n, c, 256), dtype=torch.int32, device=t.device)
+    F.call("imgxf_channel_histogram_u8", F.vp(F.view_of(t)), hist.data_ptr(), _stream())
+    return hist
+
+
+def shannon_entropy(t: torch.Tensor):
+    """compute_shannon_entropy (fall_2025/Initial_Experiments.py:95-113) of uint8 frames: the
+    256-bin histogram over all channels comes from the device; the 256-term entropy sum is
+    evaluated on the host with the reference's NumPy / SciPy expressions (density histogram,
+    normalise, -sum p log p / log 2).  Returns one float per frame."""
+    import numpy as np
+    counts = channel_histogram(t).sum(dim=1).cpu().numpy().astype(np.float64)
+    edges = np.linspace(0.0, 1.0, 257)
+    out = []
+    for row in counts:
+        dens = row / np.diff(edges) / row.sum()
+        dens = dens[dens > 0]
+        pk = dens / np.sum(dens)
+        out.append(float(np.sum(-pk * np.log(pk)) / np.log(2.0)))
+    return out
+
+
 def permute_channels(t: torch.Tensor, perm: Sequence[int]) -> torch.Tensor:
     """cv2.cvtColor channel shuffles: out[..., j] = t[..., perm[j]]."""
     t = _check_u8(t)

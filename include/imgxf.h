@@ -166,6 +166,17 @@ int imgxf_shot_noise_u8(const imgxf_view* counts_f64, double lambda, const imgxf
 int imgxf_impulse_noise_u8(const imgxf_view* src, const imgxf_view* mask_f64, double lo, double hi,
                            const imgxf_view* dst, void* stream);
 
+/* ---- AugMix point ops and histograms  fall_2025/AugMix.py:31,36,37; Initial_Experiments.py:95-113
+ * lut:       dst = lut[channel][src], lut = host table of c*256 bytes (ImageOps.posterize /
+ *            solarize / any Image.point table); copied into the launch, no device allocation.
+ * equalize:  ImageOps.equalize per frame and channel (histogram -> table -> map), all on the
+ *            device.  workspace: >= n*c*256*5 bytes, 4-byte aligned.
+ * channel_histogram: hist[n][c][256] uint32 (device, zeroed by the call) of an interleaved view. */
+int imgxf_lut_u8(const imgxf_view* src, const imgxf_view* dst, const uint8_t* lut, void* stream);
+int imgxf_equalize_u8(const imgxf_view* src, const imgxf_view* dst, void* workspace, size_t workspace_bytes,
+                      void* stream);
+int imgxf_channel_histogram_u8(const imgxf_view* src, uint32_t* hist, void* stream);
+
 /* ---- ImageFilter.BoxBlur / ImageFilter.GaussianBlur — libImaging BoxBlur.c --------------------
  * (TransformationPool.defocus_blur, cifar_image_transformations.py:72-77.)  `passes` box passes
  * along x then along y, each in exact uint32 arithmetic with replicated edges and a uint8

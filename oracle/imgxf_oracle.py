@@ -827,6 +827,88 @@ def apply_background_change(img, bg_color):
 
 
 # ----------------------------------------------------------------------------
+# AugMix operation set (fall_2025/AugMix.py:30-37) and the Shannon-entropy feature
+# (fall_2025/Initial_Experiments.py:95-113).  Pinned against PIL.ImageOps / np.histogram +
+# scipy.stats.entropy in tests/test_oracle_vs_libs.py.
+# ----------------------------------------------------------------------------
+
+def posterize_lut(bits):
+    """ImageOps.posterize (PIL/ImageOps.py): lut[i] = i & ~(2**(8-bits)-1)."""
+    mask = ~(2 ** (8 - int(bits)) - 1)
+    return np.array([i & mask for i in range(256)], np.uint8)
+
+
+def solarize_lut(threshold=128):
+    """ImageOps.solarize: i below the threshold, 255 - i from it on."""
+    return np.array([i if i < threshold else 255 - i for i in range(256)], np.uint8)
+
+
+def apply_lut(img, lut):
+    """Image.point(lut) with one 256-entry table per channel (lut: [256] or [c,256])."""
+    img = np.asarray(img, np.uint8)
+    lut = np.asarray(lut, np.uint8)
+    if img.ndim == 2:
+        return lut.reshape(-1, 256)[0][img]
+    if lut.ndim == 1:
+        return lut[img]
+    return np.stack([lut[c][img[..., c]] for c in range(img.shape[-1])], axis=-1)
+
+
+def channel_histogram(img):
+    """[c,256] int64 histogram of an HWC / HW uint8 image."""
+    img = np.asarray(img, np.uint8)
+    if img.ndim == 2:
+        img = img[..., None]
+    return np.stack([np.bincount(img[..., c].ravel(), minlength=256) for c in range(img.shape[-1])])
+
+
+def equalize_lut(h):
+    """ImageOps.equalize's table for one 256-bin histogram (PIL/ImageOps.py: equalize);
+    Image.point clips entries to 0..255 (_imaging.c getlist, CLIP8)."""
+    h = [int(v) for v in h]
+    histo = [v for v in h if v]
+    if len(histo) <= 1:
+        return np.arange(256, dtype=np.uint8)
+    step = (sum(histo) - histo[-1]) // 255
+    if not step:
+        return np.arange(256, dtype=np.uint8)
+    lut = []
+    n = step // 2
+    for i in range(256):
+        lut.append(min(n // step, 255))
+        n += h[i]
+    return np.array(lut, np.uint8)
+
+
+def equalize(img):
+    """ImageOps.equalize(img) (fall_2025/AugMix.py:36)."""
+    img = np.asarray(img, np.uint8)
+    hist = channel_histogram(img)
+    return apply_lut(img, np.stack([equalize_lut(hist[c]) for c in range(hist.shape[0])]))
+
+
+def posterize(img, bits):
+    return apply_lut(img, posterize_lut(bits))
+
+
+def solarize(img, threshold=128):
+    return apply_lut(img, solarize_lut(threshold))
+
+
+def shannon_entropy_from_histogram(counts):
+    """compute_shannon_entropy (Initial_Experiments.py:95-113) for an image whose float values
+    are v/255: np.histogram(x, bins=256, range=(0,1), density=True) puts byte v in bin v
+    (255 -> the closed last bin), so the density is counts / N / (1/256); scipy.stats.entropy
+    normalises, takes -sum(p log p) and divides by log(2)."""
+    counts = np.asarray(counts, np.float64).ravel()
+    edges = np.linspace(0.0, 1.0, 257)
+    dens = counts / np.diff(edges) / counts.sum()
+    dens = dens[dens > 0]
+    pk = dens / np.sum(dens)
+    return float(np.sum(-pk * np.log(pk)) / np.log(2.0))
+
+
+# ----------------------------------------------------------------------------
 # benchmark configs[0]: grayscale + 3x3 box blur (SURVEY §8d)
 # ----------------------------------------------------------------------------
 

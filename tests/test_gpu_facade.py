@@ -10,6 +10,7 @@ import random
 
 import numpy as np
 import pytest
+import torch
 
 from conftest import synth
 from oracle import imgxf_oracle as O
@@ -262,3 +263,96 @@ def test_pool_noise_members_follow_numpy_stream(device):
         lam = [60, 25, 12, 5, 3][sev - 1]
         noisy = np.random.poisson(arr / 255.0 * lam) / lam * 255.0
         assert np.array_equal(got, np.clip(noisy, 0, 255).astype(np.uint8))
+
+
+def test_augmix_ops_match_pillow(device):
+    """The eight AugMix operations (fall_2025/AugMix.py:30-37) == Pillow called the reference's way."""
+    import random
+    from PIL import ImageOps
+    from imagetransformations_amd import augmix as A
+    for hw in ((32, 32), (37, 61), (48, 64)):
+        a = synth(31, *hw)
+        img = Image.fromarray(a)
+        for sev in (1, 3, 5):
+            random.seed(9)
+            got = np.asarray(A.rotate(img, sev))
+            random.seed(9)
+            assert np.array_equal(got, np.asarray(img.rotate(sev * random.choice([-1, 1]))))
+            assert np.array_equal(np.asarray(A.posterize(img, sev)), np.asarray(ImageOps.posterize(img, int(sev))))
+            assert np.array_equal(np.asarray(A.shear_x(img, sev)),
+                                  np.asarray(img.transform(img.size, Image.AFFINE, (1, sev * 0.3, 0, 0, 1, 0))))
+            assert np.array_equal(np.asarray(A.shear_y(img, sev)),
+                                  np.asarray(img.transform(img.size, Image.AFFINE, (1, 0, 0, sev * 0.3, 1, 0))))
+            assert np.array_equal(np.asarray(A.translate_x(img, sev)),
+                                  np.asarray(img.transform(img.size, Image.AFFINE, (1, 0, sev * 2, 0, 1, 0))))
+            assert np.array_equal(np.asarray(A.translate_y(img, sev)),
+                                  np.asarray(img.transform(img.size, Image.AFFINE, (1, 0, 0, 0, 1, sev * 2))))
+            assert np.array_equal(np.asarray(A.solarize(img, sev)), np.asarray(ImageOps.solarize(img, int(sev * 20))))
+        assert np.array_equal(np.asarray(A.equalize(img, None)), np.asarray(ImageOps.equalize(img)))
+    # equalize corner cases: single level, dominant level with clipped table entries
+    flat = np.full((9, 7, 3), 77, np.uint8)
+    dom = np.zeros((40, 40, 3), np.uint8); dom[:2] = 5
+    for a in (flat, dom):
+        assert np.array_equal(np.asarray(A.equalize(Image.fromarray(a), None)), np.asarray(ImageOps.equalize(Image.fromarray(a))))
+
+
+def test_augmix_chain_matches_cpu_emulation(device):
+    """augmix() (AugMix.py:45-62) on the device == the same chain with Pillow + torch on the CPU
+    for the same seeds (same draws, same uint8 round trips, same float32 mixing)."""
+    import random
+    from PIL import ImageOps
+    from imagetransformations_amd import augmix as A
+
+    def ref_ops():
+        return [lambda im, s: im.rotate(s * random.choice([-1, 1])),
+                lambda im, s: ImageOps.posterize(im, int(s)),
+                lambda im, s: im.transform(im.size, Image.AFFINE, (1, s * 0.3, 0, 0, 1, 0)),
+                lambda im, s: im.transform(im.size, Image.AFFINE, (1, 0, 0, s * 0.3, 1, 0)),
+                lambda im, s: im.transform(im.size, Image.AFFINE, (1, 0, s * 2, 0, 1, 0)),
+                lambda im, s: im.transform(im.size, Image.AFFINE, (1, 0, 0, 0, 1, s * 2)),
+                lambda im, s: ImageOps.equalize(im),
+                lambda im, s: ImageOps.solarize(im, int(s * 20))]
+
+    def ref_augmix(x, severity=3, width=3, depth=-1):
+        ops_ = ref_ops()
+        ws = np.random.dirichlet([1.0] * width)
+        m = np.random.beta(1.0, 1.0)
+        mix = torch.zeros_like(x)
+        for i in range(width):
+            aug = x.clone()
+            d = depth if depth > 0 else np.random.randint(1, 4)
+            for _ in range(d):
+                op = random.choice(ops_)
+                pil = Image.fromarray(aug.mul(255).byte().permute(1, 2, 0).numpy())
+                pil = op(pil, severity)
+                aug = torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+            mix += ws[i] * aug
+        return (1 - m) * x + m * mix
+
+    x = torch.from_numpy(synth(33, 32, 32)).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    for seed in range(6):
+        random.seed(seed); np.random.seed(seed)
+        want = ref_augmix(x)
+        random.seed(seed); np.random.seed(seed)
+        got = A.augmix(x.to(device)).cpu()
+        assert torch.equal(got, want), f"seed {seed}: max diff {(got - want).abs().max().item()}"
+
+
+def test_channel_histogram_and_entropy(device):
+    from imagetransformations_amd import ops
+    from scipy.stats import entropy
+    for hw, c in (((33, 47), 3), ((64, 64), 3), ((50, 21), 1)):
+        a = synth(35, *hw, c=c)
+        stack = np.stack([a, 255 - a])
+        t = torch.from_numpy(stack if stack.ndim == 4 else stack[..., None]).to(device)
+        hist = ops.channel_histogram(t).cpu().numpy()
+        for f, arr in enumerate((a, 255 - a)):
+            arr3 = arr if arr.ndim == 3 else arr[..., None]
+            for ch in range(c):
+                assert np.array_equal(hist[f, ch], np.bincount(arr3[..., ch].ravel(), minlength=256))
+        got = ops.shannon_entropy(t)
+        for f, arr in enumerate((a, 255 - a)):
+            x = arr.astype(np.float32) / 255.0
+            hh, _ = np.histogram(x.flatten(), bins=256, range=(0, 1), density=True)
+            want = entropy(hh[hh > 0], base=2)
+            assert abs(got[f] - want) <= 1e-12 * max(1.0, abs(want))

@@ -118,3 +118,38 @@ def test_c_oracle_matches_numpy_oracle():
         assert np.array_equal(CO.rgb2l(a), g)
         assert np.array_equal(CO.sobel(g, 0), O.sobel_scipy(g, -1))
         assert np.array_equal(CO.sobel(g, 2), O.sobel_magnitude(g))
+
+
+def test_augmix_point_ops_and_entropy_vs_pil_numpy_scipy():
+    """ImageOps.posterize / solarize / equalize (AugMix.py:31,36,37) and the entropy feature
+    (Initial_Experiments.py:95-113) restated in the oracle == the libraries, incl. the
+    equalize corner cases (one level, step == 0, table entries clipped at 255)."""
+    from PIL import ImageOps
+    from scipy.stats import entropy
+    rng = np.random.default_rng(7)
+    cases = []
+    for t in range(12):
+        h, w = rng.integers(4, 60, 2)
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if t % 4 == 1:
+            a = (a // 64 * 17 + 3).astype(np.uint8)
+        if t % 4 == 2:
+            a[:] = rng.integers(0, 256)
+            a[0, 0] = [1, 200, 7]
+        if t % 4 == 3:                      # dominant low level + a few brighter pixels -> entries > 255
+            a[:] = 0
+            a[:2, :, :] = 5
+        cases.append(a)
+    cases.append(np.full((9, 7, 3), 77, np.uint8))
+    for a in cases:
+        img = Image.fromarray(a)
+        assert np.array_equal(np.asarray(ImageOps.equalize(img)), O.equalize(a))
+        for bits in range(1, 9):
+            assert np.array_equal(np.asarray(ImageOps.posterize(img, bits)), O.posterize(a, bits))
+        for thr in (0, 20, 60, 128, 255, 256):
+            assert np.array_equal(np.asarray(ImageOps.solarize(img, thr)), O.solarize(a, thr))
+        x = (a.astype(np.float32) / 255.0).transpose(2, 0, 1)
+        hist, _ = np.histogram(x.flatten(), bins=256, range=(0, 1), density=True)
+        want = entropy(hist[hist > 0], base=2)
+        got = O.shannon_entropy_from_histogram(O.channel_histogram(a).sum(0))
+        assert abs(got - want) <= 1e-12 * max(1.0, abs(want))
