@@ -51,6 +51,7 @@ SIGNATURES = {
     "imgxf_affine_u8": [_VP, _VP, _D, C.c_int, _U8, C.c_int, _VP, C.c_void_p],
     "imgxf_affine_scale_nearest_u8": [_VP, _VP, _D, _U8, C.c_void_p, C.c_size_t, C.c_void_p],
     "imgxf_lanczos_plan_create": [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
+    "imgxf_resample_plan_create": [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     "imgxf_lanczos_plan_destroy": [C.c_void_p],
     "imgxf_resize_lanczos_u8": [C.c_void_p, _VP, _VP, C.c_void_p],
     "imgxf_rgb2l_u8": [_VP, _VP, C.c_void_p],
@@ -73,6 +74,7 @@ SIGNATURES = {
     "imgxf_fill_u8": [_VP, _U8, C.c_void_p],
     "imgxf_copy_rect_u8": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "imgxf_rot90_u8": [_VP, _VP, C.c_int, C.c_void_p],
+    "imgxf_flip_u8": [_VP, _VP, C.c_int, C.c_void_p],
     "imgxf_histogram_u8": [_VP, C.c_void_p, C.c_void_p],
     "imgxf_percentile_mask_u8": [_VP, C.c_void_p, C.c_double, _VP, C.c_void_p, C.c_void_p],
     "imgxf_dilate_cross_u8": [_VP, _VP, C.c_int, C.c_void_p],

@@ -73,6 +73,20 @@ __global__ __launch_bounds__(256) void rot90_kernel(View s, View d, int turns) {
     }
 }
 
+// Image.transpose(FLIP_LEFT_RIGHT / FLIP_TOP_BOTTOM): dst(y,x) = src(y, w-1-x) or src(h-1-y, x)
+__global__ __launch_bounds__(256) void flip_kernel(View s, View d, int mode) {
+    const int64_t total = (int64_t)d.n * d.h * d.w;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int x = (int)(t % d.w);
+        const int64_t r = t / d.w;
+        const int y = (int)(r % d.h), f = (int)(r / d.h);
+        const int sx = mode == 0 ? s.w - 1 - x : x, sy = mode == 0 ? y : s.h - 1 - y;
+        const u8* sp = s.row(f, sy) + sx * s.c;
+        u8* dp = d.row(f, y) + x * d.c;
+        for (int j = 0; j < d.c; ++j) dp[j] = sp[j];
+    }
+}
+
 static inline unsigned grid_for(int64_t total) {
     int64_t blocks = (total + 255) / 256;
     return (unsigned)(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks));
@@ -122,5 +136,17 @@ IMGXF_API int imgxf_rot90_u8(const imgxf_view* src, const imgxf_view* dst, int q
     const View d = make_view(dst);
     hipLaunchKernelGGL(rot90_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0,
                        (hipStream_t)stream, make_view(src), d, quarter_turns_ccw);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_flip_u8(const imgxf_view* src, const imgxf_view* dst, int mode, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    IMGXF_CHECK(check_view(dst));
+    if (mode < 0 || mode > 1) return IMGXF_ERR_ARG;
+    if (!same_geometry(src, dst)) return IMGXF_ERR_SHAPE;
+    if (empty_view(dst)) return IMGXF_OK;
+    const View d = make_view(dst);
+    hipLaunchKernelGGL(flip_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0,
+                       (hipStream_t)stream, make_view(src), d, mode);
     return launch_status();
 }

@@ -41,13 +41,50 @@ static inline double lanczos_filter(double x) {
     if (-3.0 <= x && x < 3.0) return sinc_filter(x) * sinc_filter(x / 3);
     return 0.0;
 }
+// the other filters of libImaging Resample.c (Image.resize's default is BICUBIC)
+static inline double box_filter(double x) { return (x > -0.5 && x <= 0.5) ? 1.0 : 0.0; }
+static inline double bilinear_filter(double x) {
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+static inline double hamming_filter(double x) {
+    if (x < 0.0) x = -x;
+    if (x == 0.0) return 1.0;
+    if (x >= 1.0) return 0.0;
+    x = x * M_PI;
+    return sin(x) / x * (0.54f + 0.46f * cos(x));      // float literals, as in Resample.c
+}
+static inline double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+static inline double filter_support(int filter) {
+    switch (filter) {
+        case IMGXF_RESAMPLE_BOX: return 0.5;
+        case IMGXF_RESAMPLE_BILINEAR: case IMGXF_RESAMPLE_HAMMING: return 1.0;
+        case IMGXF_RESAMPLE_BICUBIC: return 2.0;
+        default: return 3.0;
+    }
+}
+static inline double filter_value(int filter, double x) {
+    switch (filter) {
+        case IMGXF_RESAMPLE_BOX: return box_filter(x);
+        case IMGXF_RESAMPLE_BILINEAR: return bilinear_filter(x);
+        case IMGXF_RESAMPLE_HAMMING: return hamming_filter(x);
+        case IMGXF_RESAMPLE_BICUBIC: return bicubic_filter(x);
+        default: return lanczos_filter(x);
+    }
+}
 
 // precompute_coeffs + normalize_coeffs_8bpc (whole-image box)
-static int build_coeffs(int in_size, int out_size, std::vector<int>& bounds, std::vector<int>& kk) {
+static int build_coeffs(int in_size, int out_size, int filter, std::vector<int>& bounds, std::vector<int>& kk) {
     double scale, filterscale;
     filterscale = scale = (double)in_size / out_size;
     if (filterscale < 1.0) filterscale = 1.0;
-    const double support = 3.0 * filterscale;
+    const double support = filter_support(filter) * filterscale;
     const int ksize = (int)ceil(support) * 2 + 1;
     bounds.assign((size_t)out_size * 2, 0);
     kk.assign((size_t)out_size * ksize, 0);
@@ -62,7 +99,7 @@ static int build_coeffs(int in_size, int out_size, std::vector<int>& bounds, std
         if (xmax > in_size) xmax = in_size;
         xmax -= xmin;
         for (int x = 0; x < xmax; ++x) {
-            const double w = lanczos_filter((x + xmin - center + 0.5) * ss);
+            const double w = filter_value(filter, (x + xmin - center + 0.5) * ss);
             k[x] = w;
             ww += w;
         }
@@ -289,9 +326,15 @@ static int upload(const std::vector<int>& v, int** dptr) {
 
 IMGXF_API int imgxf_lanczos_plan_create(imgxf_lanczos_plan** plan, int in_h, int in_w, int out_h,
                                         int out_w, int c, int max_frames) {
+    return imgxf_resample_plan_create(plan, in_h, in_w, out_h, out_w, c, max_frames, IMGXF_RESAMPLE_LANCZOS);
+}
+
+IMGXF_API int imgxf_resample_plan_create(imgxf_lanczos_plan** plan, int in_h, int in_w, int out_h,
+                                         int out_w, int c, int max_frames, int filter) {
     if (!plan) return IMGXF_ERR_NULL;
     *plan = nullptr;
     if (in_h < 1 || in_w < 1 || out_h < 1 || out_w < 1 || max_frames < 1) return IMGXF_ERR_ARG;
+    if (filter < IMGXF_RESAMPLE_LANCZOS || filter > IMGXF_RESAMPLE_HAMMING) return IMGXF_ERR_ARG;
     if (c != 1 && c != 3 && c != 4) return IMGXF_ERR_UNSUPPORTED;
     imgxf_lanczos_plan* p = new imgxf_lanczos_plan();
     memset(p, 0, sizeof(*p));
@@ -302,7 +345,7 @@ IMGXF_API int imgxf_lanczos_plan_create(imgxf_lanczos_plan** plan, int in_h, int
     int rc = IMGXF_OK;
     if (p->need_h) {
         std::vector<int> b, k;
-        p->ksx = build_coeffs(in_w, out_w, b, k);
+        p->ksx = build_coeffs(in_w, out_w, filter, b, k);
         if ((rc = upload(b, &p->d_bounds_x)) == IMGXF_OK) rc = upload(k, &p->d_kk_x);
         const int kp = p->ksx <= 8 ? 8 : (p->ksx <= 12 ? 12 : (p->ksx <= 16 ? 16 : 0));
         if (rc == IMGXF_OK && c == 3 && kp && in_w >= kp) {
@@ -314,7 +357,7 @@ IMGXF_API int imgxf_lanczos_plan_create(imgxf_lanczos_plan** plan, int in_h, int
     }
     if (rc == IMGXF_OK && p->need_v) {
         std::vector<int> b, k;
-        p->ksy = build_coeffs(in_h, out_h, b, k);
+        p->ksy = build_coeffs(in_h, out_h, filter, b, k);
         if ((rc = upload(b, &p->d_bounds_y)) == IMGXF_OK) rc = upload(k, &p->d_kk_y);
         const int kp = p->ksy;
         if (rc == IMGXF_OK && in_h >= kp) {

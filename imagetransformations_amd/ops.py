@@ -16,7 +16,9 @@ import torch
 
 from . import _ffi as F
 
-NEAREST, BILINEAR, BICUBIC = F.FILTER_NEAREST, F.FILTER_BILINEAR, F.FILTER_BICUBIC
+NEAREST, BILINEAR, BICUBIC = F.FILTER_NEAREST, F.FILTER_BILINEAR, F.FILTER_BICUBIC   # affine() filter codes
+# resize() filters carry Pillow's own Image.Resampling values
+RESAMPLE_LANCZOS, RESAMPLE_BILINEAR, RESAMPLE_BICUBIC, RESAMPLE_BOX, RESAMPLE_HAMMING = 1, 2, 3, 4, 5
 REFLECT_101, REFLECT = F.BORDER_REFLECT_101, F.BORDER_REFLECT
 
 
@@ -186,6 +188,14 @@ def rotate_zoom_matrix(w: int, h: int, angle_deg: float, zoom: float) -> list[fl
     return [c, -s, cx - (c * cx - s * cy), s, c, cy - (s * cx + c * cy)]
 
 
+def flip(t: torch.Tensor, top_bottom: bool = False) -> torch.Tensor:
+    """Image.transpose(FLIP_LEFT_RIGHT) (default) / FLIP_TOP_BOTTOM."""
+    t = _check_u8(t)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_flip_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), 1 if top_bottom else 0, _stream())
+    return out
+
+
 def rot90(t: torch.Tensor, quarter_turns_ccw: int) -> torch.Tensor:
     t = _check_u8(t)
     h, w, _ = _hwc(t)
@@ -217,8 +227,8 @@ class _PlanCache:
     def __init__(self):
         self._plans: dict = {}
 
-    def get(self, in_h, in_w, out_h, out_w, c, n, device_index):
-        key = (in_h, in_w, out_h, out_w, c, device_index)
+    def get(self, in_h, in_w, out_h, out_w, c, n, device_index, resample=1):
+        key = (in_h, in_w, out_h, out_w, c, device_index, resample)
         ent = self._plans.get(key)
         if ent is not None and ent[1] >= n:
             return ent[0]
@@ -227,7 +237,7 @@ class _PlanCache:
         import ctypes
         handle = ctypes.c_void_p()
         with torch.cuda.device(device_index):
-            F.call("imgxf_lanczos_plan_create", ctypes.byref(handle), in_h, in_w, out_h, out_w, c, n)
+            F.call("imgxf_resample_plan_create", ctypes.byref(handle), in_h, in_w, out_h, out_w, c, n, resample)
         self._plans[key] = (handle, n)
         return handle
 
@@ -242,6 +252,15 @@ _plans = _PlanCache()
 
 def resize_lanczos(t: torch.Tensor, size: tuple[int, int]) -> torch.Tensor:
     """img.resize((nw, nh), Image.Resampling.LANCZOS) — transformation.py:179."""
+    return resize(t, size, RESAMPLE_LANCZOS)
+
+
+def resize(t: torch.Tensor, size: tuple[int, int], resample: int = RESAMPLE_BICUBIC) -> torch.Tensor:
+    """Image.resize(size, resample) for the convolution filters of Resample.c (Pillow's
+    Resampling values: LANCZOS=1, BILINEAR=2, BICUBIC=3 (Image.resize's default), BOX=4,
+    HAMMING=5); NEAREST resize is an affine scale (`affine`)."""
+    if resample not in (RESAMPLE_LANCZOS, RESAMPLE_BILINEAR, RESAMPLE_BICUBIC, RESAMPLE_BOX, RESAMPLE_HAMMING):
+        raise ValueError(f"Unknown resampling filter ({resample})")
     t = _check_u8(t)
     h, w, c = _hwc(t)
     nw, nh = int(size[0]), int(size[1])
@@ -251,7 +270,7 @@ def resize_lanczos(t: torch.Tensor, size: tuple[int, int]) -> torch.Tensor:
     out = _like(t, nh, nw)
     if n == 0:
         return out
-    plan = _plans.get(h, w, nh, nw, c, n, t.device.index or 0)
+    plan = _plans.get(h, w, nh, nw, c, n, t.device.index or 0, int(resample))
     F.call("imgxf_resize_lanczos_u8", plan, F.vp(F.view_of(t)), F.vp(F.view_of(out)), _stream())
     return out
 

@@ -123,6 +123,13 @@ int imgxf_lanczos_plan_create(imgxf_lanczos_plan** plan, int in_h, int in_w, int
 int imgxf_lanczos_plan_destroy(imgxf_lanczos_plan* plan);
 int imgxf_resize_lanczos_u8(const imgxf_lanczos_plan* plan, const imgxf_view* src,
                             const imgxf_view* dst, void* stream);
+/* The same machinery with Resample.c's other filters — Image.resize's default BICUBIC is what
+ * rand_crop uses (fall_2025/transformations_code:43-48).  `filter` takes Pillow's Resampling
+ * values; the plan is run and destroyed with the two calls above. */
+enum { IMGXF_RESAMPLE_LANCZOS = 1, IMGXF_RESAMPLE_BILINEAR = 2, IMGXF_RESAMPLE_BICUBIC = 3,
+       IMGXF_RESAMPLE_BOX = 4, IMGXF_RESAMPLE_HAMMING = 5 };
+int imgxf_resample_plan_create(imgxf_lanczos_plan** plan, int in_h, int in_w, int out_h,
+                               int out_w, int c, int max_frames, int filter);
 
 /* ---- a6: elementwise colour maps ------------------------------------------------------*/
 /* Pillow convert('L') transformation.py:336: (19595R+38470G+7471B+0x8000)>>16. src c in {3,4}, dst c==1 */
@@ -207,6 +214,9 @@ int imgxf_copy_rect_u8(const imgxf_view* src, const imgxf_view* dst, int sx, int
  * quarter_turns_ccw in {1,2,3}. */
 int imgxf_rot90_u8(const imgxf_view* src, const imgxf_view* dst, int quarter_turns_ccw,
                    void* stream);
+/* Image.transpose(FLIP_LEFT_RIGHT) (mode 0; vert_flip, fall_2025/transformations_code:39-41) or
+ * FLIP_TOP_BOTTOM (mode 1).  Same geometry in and out. */
+int imgxf_flip_u8(const imgxf_view* src, const imgxf_view* dst, int mode, void* stream);
 
 /* ---- mask stage of apply_background_change  transformation.py:340-341 -----------------*/
 /* 256-bin histogram per frame of a c==1 view into hist[n][256] (uint32, device, zeroed by the call). */

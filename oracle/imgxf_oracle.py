@@ -601,13 +601,53 @@ def _lanczos3(x):
     return 0.0
 
 
-def lanczos_coeffs(in_size, out_size):
+# the other convolution filters of Resample.c; keys are Pillow's Image.Resampling values
+RESAMPLE_LANCZOS, RESAMPLE_BILINEAR, RESAMPLE_BICUBIC, RESAMPLE_BOX, RESAMPLE_HAMMING = 1, 2, 3, 4, 5
+
+
+def _box_filter(x):
+    return 1.0 if -0.5 < x <= 0.5 else 0.0
+
+
+def _bilinear_filter(x):
+    x = abs(x)
+    return 1.0 - x if x < 1.0 else 0.0
+
+
+def _hamming_filter(x):
+    x = abs(x)
+    if x == 0.0:
+        return 1.0
+    if x >= 1.0:
+        return 0.0
+    x = x * math.pi
+    # Resample.c writes the window constants as float literals: 0.54f + 0.46f * cos(x)
+    return math.sin(x) / x * (float(np.float32(0.54)) + float(np.float32(0.46)) * math.cos(x))
+
+
+def _bicubic_filter(x):
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+_FILTERS = {RESAMPLE_LANCZOS: (_lanczos3, 3.0), RESAMPLE_BILINEAR: (_bilinear_filter, 1.0),
+            RESAMPLE_BICUBIC: (_bicubic_filter, 2.0), RESAMPLE_BOX: (_box_filter, 0.5),
+            RESAMPLE_HAMMING: (_hamming_filter, 1.0)}
+
+
+def lanczos_coeffs(in_size, out_size, resample=RESAMPLE_LANCZOS):
     """precompute_coeffs + normalize_coeffs_8bpc for the whole-image box.
     Returns (bounds[out,2] int32 (xmin, count), kk[out,ksize] int32, ksize)."""
+    filt, fsupport = _FILTERS[resample]
     scale = filterscale = float(in_size) / out_size
     if filterscale < 1.0:
         filterscale = 1.0
-    support = 3.0 * filterscale
+    support = fsupport * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((out_size, 2), np.int32)
     kk = np.zeros((out_size, ksize), np.int32)
@@ -621,7 +661,7 @@ def lanczos_coeffs(in_size, out_size):
         if xmax > in_size:
             xmax = in_size
         xmax -= xmin
-        ws = [_lanczos3((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ws = [filt((x + xmin - center + 0.5) * ss) for x in range(xmax)]
         ww = 0.0
         for v in ws:
             ww += v
@@ -635,10 +675,10 @@ def lanczos_coeffs(in_size, out_size):
     return bounds, kk, ksize
 
 
-def _resample_axis0(a, out_size):
+def _resample_axis0(a, out_size, resample=RESAMPLE_LANCZOS):
     """Resample along axis 0 of an (n, m, c) uint8 array."""
     n = a.shape[0]
-    bounds, kk, ksize = lanczos_coeffs(n, out_size)
+    bounds, kk, ksize = lanczos_coeffs(n, out_size, resample)
     src = a.astype(np.int64)
     acc = np.full((out_size,) + a.shape[1:], 1 << (PRECISION_BITS - 1), np.int64)
     idx = bounds[:, 0][:, None] + np.arange(ksize)[None, :]
@@ -649,16 +689,21 @@ def _resample_axis0(a, out_size):
 
 
 def resize_lanczos(img, size):
-    """img.resize(size, LANCZOS): horizontal pass, uint8 intermediate, vertical pass;
+    """img.resize(size, LANCZOS) — transformation.py:179."""
+    return resize(img, size, RESAMPLE_LANCZOS)
+
+
+def resize(img, size, resample=RESAMPLE_BICUBIC):
+    """img.resize(size, resample): horizontal pass, uint8 intermediate, vertical pass;
     a pass is skipped when that dimension is unchanged (Resample.c ImagingResample)."""
     a, was2d = _as3d(img)
     h, w, _ = a.shape
     nw, nh = size
     out = a
     if nw != w:
-        out = np.ascontiguousarray(_resample_axis0(out.transpose(1, 0, 2), nw).transpose(1, 0, 2))
+        out = np.ascontiguousarray(_resample_axis0(out.transpose(1, 0, 2), nw, resample).transpose(1, 0, 2))
     if nh != h:
-        out = _resample_axis0(out, nh)
+        out = _resample_axis0(out, nh, resample)
     out = np.ascontiguousarray(out) if out is not a else a.copy()
     return out[:, :, 0] if was2d else out
 
@@ -831,6 +876,19 @@ def apply_background_change(img, bg_color):
 # (fall_2025/Initial_Experiments.py:95-113).  Pinned against PIL.ImageOps / np.histogram +
 # scipy.stats.entropy in tests/test_oracle_vs_libs.py.
 # ----------------------------------------------------------------------------
+
+def vert_flip(img):
+    """fall_2025/transformations_code:39-41: img.transpose(FLIP_LEFT_RIGHT)."""
+    return np.ascontiguousarray(np.asarray(img)[:, ::-1])
+
+
+def rand_crop(img, x, y):
+    """fall_2025/transformations_code:43-48 for the drawn corner (x, y):
+    img.crop((x, y, x+cs, y+cs)).resize((32, 32)) with cs = int(0.78 * w), BICUBIC default."""
+    a = np.asarray(img, np.uint8)
+    cs = int(0.78 * a.shape[1])
+    return resize(np.ascontiguousarray(a[y:y + cs, x:x + cs]), (32, 32), RESAMPLE_BICUBIC)
+
 
 def posterize_lut(bits):
     """ImageOps.posterize (PIL/ImageOps.py): lut[i] = i & ~(2**(8-bits)-1)."""

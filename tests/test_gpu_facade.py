@@ -356,3 +356,31 @@ def test_channel_histogram_and_entropy(device):
             hh, _ = np.histogram(x.flatten(), bins=256, range=(0, 1), density=True)
             want = entropy(hh[hh > 0], base=2)
             assert abs(got[f] - want) <= 1e-12 * max(1.0, abs(want))
+
+
+def test_transformations_code_extras(device):
+    """vert_flip / rand_crop / apply_random_zoom (fall_2025/transformations_code:39-52) and
+    ops.resize with every Resample.c filter == Pillow."""
+    from imagetransformations_amd import ops, transformations_code as T
+    for hw in ((32, 32), (37, 61), (96, 64)):
+        a = synth(41, *hw)
+        img = Image.fromarray(a)
+        assert np.array_equal(np.asarray(T.vert_flip(img)), np.asarray(img.transpose(Image.FLIP_LEFT_RIGHT)))
+        if hw[0] >= int(0.78 * hw[1]):
+            np.random.seed(3)
+            got = np.asarray(T.rand_crop(img))
+            np.random.seed(3)
+            w, h = img.size
+            cs = int(0.78 * w)
+            x, y = np.random.randint(0, w - cs + 1), np.random.randint(0, h - cs + 1)
+            assert np.array_equal(got, np.asarray(img.crop((x, y, x + cs, y + cs)).resize((32, 32))))
+        assert np.array_equal(np.asarray(T.apply_random_zoom(img, 1.1)), O.apply_scale(a, 1.1))
+        t = torch.from_numpy(np.stack([a, a[::-1].copy()])).to(device)
+        for size in ((32, 32), (hw[1] + 9, hw[0] - 3), (hw[1], hw[0] + 5), (7, 5)):
+            for flt in (1, 2, 3, 4, 5):
+                got = ops.resize(t, size, flt).cpu().numpy()
+                assert np.array_equal(got[0], np.asarray(img.resize(size, flt))), (hw, size, flt)
+                assert np.array_equal(got[1], np.asarray(Image.fromarray(a[::-1].copy()).resize(size, flt)))
+        assert np.array_equal(ops.flip(t, top_bottom=True).cpu().numpy()[0], a[::-1])
+    with pytest.raises(AttributeError):
+        T.apply_perspective_warp

@@ -153,3 +153,22 @@ def test_augmix_point_ops_and_entropy_vs_pil_numpy_scipy():
         want = entropy(hist[hist > 0], base=2)
         got = O.shannon_entropy_from_histogram(O.channel_histogram(a).sum(0))
         assert abs(got - want) <= 1e-12 * max(1.0, abs(want))
+
+
+def test_resize_filters_and_flip_vs_pillow():
+    """Image.resize with every convolution filter of Resample.c (BICUBIC is the default that
+    rand_crop uses, fall_2025/transformations_code:43-48) and FLIP_LEFT_RIGHT (:39-41)."""
+    rng = np.random.default_rng(11)
+    for t in range(6):
+        h, w = rng.integers(5, 60, 2)
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img = Image.fromarray(a)
+        for size in ((32, 32), (int(w * 1.3) + 1, int(h * 0.7) + 1), (w, h + 3), (7, 5)):
+            for flt in (O.RESAMPLE_LANCZOS, O.RESAMPLE_BILINEAR, O.RESAMPLE_BICUBIC, O.RESAMPLE_BOX, O.RESAMPLE_HAMMING):
+                assert np.array_equal(np.asarray(img.resize(size, flt)), O.resize(a, size, flt)), (h, w, size, flt)
+        assert np.array_equal(np.asarray(img.resize((32, 32))), O.resize(a, (32, 32)))      # default filter
+        assert np.array_equal(np.asarray(img.transpose(Image.FLIP_LEFT_RIGHT)), O.vert_flip(a))
+        cs = int(0.78 * w)
+        if cs >= 1 and h >= cs:
+            x, y = int(rng.integers(0, w - cs + 1)), int(rng.integers(0, h - cs + 1))
+            assert np.array_equal(np.asarray(img.crop((x, y, x + cs, y + cs)).resize((32, 32))), O.rand_crop(a, x, y))
