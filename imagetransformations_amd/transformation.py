@@ -56,16 +56,21 @@ def _download(t: torch.Tensor) -> Image.Image:
     return Image.fromarray(t.cpu().numpy())
 
 
+def _hw(t: torch.Tensor):
+    """(height, width) of a [H,W], [H,W,C] or [N,H,W,C] tensor."""
+    return (t.shape[0], t.shape[1]) if t.dim() == 2 else (t.shape[-3], t.shape[-2])
+
+
 def _drop_alpha(t: torch.Tensor) -> torch.Tensor:
     return ops.permute_channels(t, (0, 1, 2)) if t.dim() == 3 and t.shape[2] == 4 else t
 
 
 # ------------------------------------------------------------------ scale (:173-196)
-def apply_scale(img: Image.Image, scale_factor: float) -> Image.Image:
-    width, height = img.size
+def _scale_t(t: torch.Tensor, scale_factor: float) -> torch.Tensor:
+    """apply_scale on a [H,W,C] or [N,H,W,C] device tensor."""
+    height, width = _hw(t)
     new_width = int(width * scale_factor)
     new_height = int(height * scale_factor)
-    t = _upload(img)
     scaled = ops.resize_lanczos(t, (new_width, new_height))
     if scale_factor > 1.0:
         left = (new_width - width) // 2
@@ -76,12 +81,20 @@ def apply_scale(img: Image.Image, scale_factor: float) -> Image.Image:
         ops.copy_rect(scaled, canvas, 0, 0, (width - new_width) // 2, (height - new_height) // 2,
                       new_width, new_height)
         scaled = canvas
-    return _download(scaled)
+    return scaled
+
+
+def apply_scale(img: Image.Image, scale_factor: float) -> Image.Image:
+    return _download(_scale_t(_upload(img), scale_factor))
 
 
 # ------------------------------------------------------------------ rotation (:198-201)
+def _rotation_t(t: torch.Tensor, angle: float) -> torch.Tensor:
+    return ops.rotate(t, -angle, ops.NEAREST, fillcolor=(0, 0, 0))
+
+
 def apply_rotation(img: Image.Image, angle: float) -> Image.Image:
-    return _download(ops.rotate(_upload(img), -angle, ops.NEAREST, fillcolor=(0, 0, 0)))
+    return _download(_rotation_t(_upload(img), angle))
 
 
 # ------------------------------------------------------------------ contrast (:203-210)
@@ -93,23 +106,33 @@ def apply_contrast(img: Image.Image, contrast_amount: float) -> Image.Image:
 
 
 # ------------------------------------------------------------------ shear (:212-226)
-def apply_shear(img: Image.Image, shear_factor: float) -> Image.Image:
-    width, height = img.size
+def _shear_t(t: torch.Tensor, shear_factor: float) -> torch.Tensor:
+    height, width = _hw(t)
     shift_in_pixels = int(math.ceil(shear_factor * height))
     matrix = (1, shear_factor, -shift_in_pixels if shear_factor > 0 else 0, 0, 1, 0)
-    out = ops.affine(_upload(img), matrix, (width + shift_in_pixels, height), ops.BICUBIC,
-                     fillcolor=(255, 255, 255))
-    return _download(out)
+    return ops.affine(t, matrix, (width + shift_in_pixels, height), ops.BICUBIC, fillcolor=(255, 255, 255))
+
+
+def apply_shear(img: Image.Image, shear_factor: float) -> Image.Image:
+    return _download(_shear_t(_upload(img), shear_factor))
 
 
 # ------------------------------------------------------------------ blur (:228-257)
-def apply_blur(img: Image.Image, blur_radius: float) -> Image.Image:
+def _blur_ksize(blur_radius: float) -> int:
+    """The reference's kernel-size rule (:239-246); 0 means "return the input object"."""
     ksize = int(blur_radius * 6)
     if ksize % 2 == 0:
         ksize += 1
     if ksize < 3 and blur_radius > 0:
         ksize = 3
     elif blur_radius == 0:
+        return 0
+    return ksize
+
+
+def apply_blur(img: Image.Image, blur_radius: float) -> Image.Image:
+    ksize = _blur_ksize(blur_radius)
+    if ksize == 0:
         return img          # the reference hands back the input object itself (:245-246)
     t = _drop_alpha(_upload(img))
     return _download(ops.gaussian_blur(t, ksize, blur_radius))
@@ -134,9 +157,8 @@ def apply_gaussian_noise(img: Image.Image, noise_std: float) -> Image.Image:
 
 
 # ------------------------------------------------------------------ translation (:284-307)
-def apply_translation(img: Image.Image, tx: float, ty: float) -> Image.Image:
-    width, height = img.size
-    t = _upload(img.convert('RGB') if img.mode != 'RGB' else img)
+def _translation_t(t: torch.Tensor, tx: float, ty: float) -> torch.Tensor:
+    height, width = _hw(t)
     result = ops.new(t, height, width, (0, 0, 0))
     paste_x, paste_y = int(tx), int(ty)
     crop_left, crop_top = max(0, -paste_x), max(0, -paste_y)
@@ -144,7 +166,11 @@ def apply_translation(img: Image.Image, tx: float, ty: float) -> Image.Image:
     if crop_left < crop_right and crop_top < crop_bottom:
         ops.copy_rect(t, result, crop_left, crop_top, max(0, paste_x), max(0, paste_y),
                       crop_right - crop_left, crop_bottom - crop_top)
-    return _download(result)
+    return result
+
+
+def apply_translation(img: Image.Image, tx: float, ty: float) -> Image.Image:
+    return _download(_translation_t(_upload(img.convert('RGB') if img.mode != 'RGB' else img), tx, ty))
 
 
 def apply_camera_distance(img: Image.Image, distance_factor: float) -> Image.Image:   # :309-314
@@ -247,4 +273,75 @@ def apply_all_transformations(images):
             total_transforms += 1
         if (i + 1) % 1000 == 0:
             print(f"Processed {i + 1}/{len(images)} original images, created {total_transforms} transformed images")
+    return transformed_images
+
+
+def apply_all_transformations_batched(images):
+    """`apply_all_transformations` with the work grouped for the GPU: same draws (`random` per
+    transform type per image, `np.random` for the noise, in the reference's order), same file
+    names, same outputs in the same order — but every image is uploaded once, and all images
+    of one size that drew the same (type, value) go through ONE batched launch.  Images that
+    are not 8-bit RGB take the per-image path.  images: [(PIL image, path)]."""
+    dev = _device()
+    plans, noise = [], {}
+    for i, (img, path) in enumerate(images):
+        name = os.path.splitext(os.path.basename(path))[0]
+        plan = plan_transformations(name)
+        plans.append(plan)
+        for k, (transform_type, args, _) in enumerate(plan):
+            if transform_type == 'gaussian_noise':      # same np.random stream as the per-image loop
+                w, h = img.size
+                noise[(i, k)] = np.random.normal(0, args[0] * 255, (h, w, 3)).astype(np.float32)
+
+    results = [[None] * len(p) for p in plans]
+    by_size = {}
+    for i, (img, _) in enumerate(images):
+        if img.mode == 'RGB':
+            by_size.setdefault(img.size, []).append(i)
+        else:                                           # rare: keep the reference's behaviour exactly
+            for k, (transform_type, args, _) in enumerate(plans[i]):
+                if transform_type == 'gaussian_noise':
+                    raise NotImplementedError("batched driver expects RGB images (load_data converts them)")
+                fn = apply_translation if transform_type == 'translation' else _DISPATCH[transform_type]
+                results[i][k] = fn(img, *args)
+
+    tensor_fns = {
+        'scale': _scale_t,
+        'rotation': _rotation_t,
+        'lighten_darken': lambda t, b: ops.brightness(t, 1.0 + b),
+        'contrast': lambda t, a: ops.scale_abs(t, a, 0.0),
+        'shear': _shear_t,
+        'translation': _translation_t,
+    }
+    for size, members in by_size.items():
+        frames = torch.from_numpy(np.stack([np.array(images[i][0]) for i in members])).to(dev)
+        groups = {}
+        for row, i in enumerate(members):
+            for k, (transform_type, args, _) in enumerate(plans[i]):
+                groups.setdefault((transform_type, args), []).append((row, i, k))
+        for (transform_type, args), entries in groups.items():
+            rows = torch.tensor([e[0] for e in entries], device=dev)
+            batch = frames.index_select(0, rows)
+            if transform_type == 'blur':
+                ksize = _blur_ksize(args[0])
+                if ksize == 0:
+                    for _, i, k in entries:
+                        results[i][k] = images[i][0]    # the input object itself (:245-246)
+                    continue
+                out = ops.gaussian_blur(batch, ksize, args[0])
+            elif transform_type == 'gaussian_noise':
+                z = torch.from_numpy(np.stack([noise[(i, k)] for _, i, k in entries])).to(dev)
+                out = ops.add_noise(batch, z)
+            else:
+                out = tensor_fns[transform_type](batch, *args)
+            host = out.cpu().numpy()
+            for j, (_, i, k) in enumerate(entries):
+                results[i][k] = Image.fromarray(host[j])
+
+    transformed_images = []
+    for i, plan in enumerate(plans):
+        for k, (_, _, new_filename) in enumerate(plan):
+            if output_dir is not None:
+                results[i][k].save(os.path.join(output_dir, new_filename))
+            transformed_images.append(results[i][k])
     return transformed_images

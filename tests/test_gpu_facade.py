@@ -384,3 +384,24 @@ def test_transformations_code_extras(device):
         assert np.array_equal(ops.flip(t, top_bottom=True).cpu().numpy()[0], a[::-1])
     with pytest.raises(AttributeError):
         T.apply_perspective_warp
+
+
+def test_batched_driver_equals_per_image_driver(device):
+    """apply_all_transformations_batched: same draws, same file-name order, same pixels as the
+    per-image driver (the reference's loop, transformation.py:92-170) for mixed image sizes."""
+    from imagetransformations_amd import transformation as T
+    imgs = [(Image.fromarray(synth(50 + i, *hw)), f"/data/n0{i}/img_{i}.JPEG")
+            for i, hw in enumerate([(32, 32), (48, 64), (32, 32), (37, 61), (48, 64), (32, 32), (32, 32)])]
+    for seed in (0, 1, 2):
+        random.seed(seed); np.random.seed(seed)
+        want = T.apply_all_transformations(imgs)
+        random.seed(seed); np.random.seed(seed)
+        got = T.apply_all_transformations_batched(imgs)
+        assert len(got) == len(want) == 8 * len(imgs)
+        for a, b in zip(got, want):
+            assert a.size == b.size and a.mode == b.mode
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+        # blur radius 0 hands back the input object itself in both drivers
+        for j, (a, b) in enumerate(zip(got, want)):
+            if b is imgs[j // 8][0]:
+                assert a is b
