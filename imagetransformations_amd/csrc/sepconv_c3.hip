@@ -8,16 +8,6 @@ int sepconv_c3(int R, const View& s, const View& d, const View& df, const Taps& 
                int border, hipStream_t st) {
     static const int rpw_env = getenv("IMGXF_MARCH_RPW") ? atoi(getenv("IMGXF_MARCH_RPW")) : 0;
     static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
-    static const int j_env = getenv("IMGXF_MARCH_J") ? atoi(getenv("IMGXF_MARCH_J")) : 0;   // tuning knob
-    if (!no_march && R == 2 && j_env && march_eligible(s, d, df, 3, R, border)) {
-        switch (j_env) {
-            case 3: return launch_sepconv_march<3, 2, 3>(s, d, df, taps, st, rpw_env);
-            case 4: return launch_sepconv_march<3, 2, 4>(s, d, df, taps, st, rpw_env);
-            case 8: return launch_sepconv_march<3, 2, 8>(s, d, df, taps, st, rpw_env);
-            case 12: return launch_sepconv_march<3, 2, 12>(s, d, df, taps, st, rpw_env);
-            default: break;
-        }
-    }
     if (!no_march && march_eligible(s, d, df, 3, R, border)) {
         switch (R) {
 #define IMGXF_M(r) case r: return launch_sepconv_march<3, r>(s, d, df, taps, st, rpw_env);
