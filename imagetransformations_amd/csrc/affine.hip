@@ -567,14 +567,12 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
     if (clean) {
         const int Xb = (int)((XL + 32768) >> 16), Yb = (int)((YL + 32768) >> 16);   // rounded: |error| <= 2^-25
         u32 od[C] = {0u, 0u, 0u};
-        u32 need = 0;                                    // bit k: redo pixel k; bit 4+k: its support is unsure
+        u32 need = 0;                                    // bit k: pixel k is handed to the slow path
         float vf[DBG ? 4 : 1][C];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int X32 = Xb + P.sx[k], Y32 = Yb + P.sy[k];
             const u32 fx = (u32)X32 & (FONE - 1), fy = (u32)Y32 & (FONE - 1);
-            const u32 hx = (fx & (FHALF - 1)) - CG32, hy = (fy & (FHALF - 1)) - CG32;
-            const bool unsure = max(hx, hy) >= (u32)(FHALF - 2 * CG32);
             const f32x2 dd = f32x2{(float)fx, (float)fy} * f32x2{5.9604644775390625e-08f, 5.9604644775390625e-08f};   // 2^-24
             const float dxf = dd.x, dyf = dd.y;
             const int li = (Y32 >> 24) * PITCH + (X32 >> 24);
@@ -594,15 +592,19 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
             od[(k * C + 0) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(flrg.x, (k * C + 0) & 3, od[(k * C + 0) >> 2]);
             od[(k * C + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(flrg.y, (k * C + 1) & 3, od[(k * C + 1) >> 2]);
             od[(k * C + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(flb, (k * C + 2) & 3, od[(k * C + 2) >> 2]);
-            float dist = 0.0f;
+            // one float test flags both kinds of hand-back: a coordinate whose fraction is within
+            // GUARD of 0 or 1 (floor() of the 8.24 value could differ from libImaging's; interior
+            // tiles have no bounds test, so half-integers do not matter) and, when PRECISE, a value
+            // within GUARD of an integer.  The slow path below sorts out which it was.
+            const f32x2 cd = dd - f32x2{0.5f, 0.5f};
+            float dist = fmaxf(fabsf(cd.x), fabsf(cd.y));
             if (PRECISE) {
                 const f32x2 urg = (vrg - flrg) - f32x2{0.5f, 0.5f};
                 const float ub = (vb - flb) - 0.5f;
-                dist = fmaxf(fmaxf(fabsf(urg.x), fabsf(urg.y)), fabsf(ub));
+                dist = fmaxf(dist, fmaxf(fmaxf(fabsf(urg.x), fabsf(urg.y)), fabsf(ub)));
             }
             if (DBG) { vf[k][0] = vrg.x; vf[k][1] = vrg.y; vf[k][2] = vb; }
-            const bool near_int = PRECISE && dist > 0.5f - GUARD;
-            need |= (unsure ? 0x11u << k : 0u) | (near_int ? 1u << k : 0u);
+            need |= dist > 0.5f - GUARD ? 1u << k : 0u;
         }
         if (need) {
 #pragma unroll
@@ -610,12 +612,16 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
                 if ((need >> k) & 1u) {
                     u8 px[C]; float vv[C];
                     bool have = true;
-                    if ((need >> (4 + k)) & 1u) {
+                    const int X32 = Xb + P.sx[k], Y32 = Yb + P.sy[k];
+                    const u32 gx = (((u32)X32 + CG32) & (FONE - 1)), gy = (((u32)Y32 + CG32) & (FONE - 1));
+                    if (min(gx, gy) < 2u * CG32) {
+                        // the 8.24 coordinate is within 2^-18 of an integer: its floor is not certain
                         exact_pixel(x0 + k, px, vv);
+                    } else if (!PRECISE) {
+                        have = false;                    // certain support, fp32 value stands
                     } else {
                         // the support is certain: only dx, dy and the lerps need libImaging's fp64
                         // sequence, on the taps re-read from LDS.  A flat support is exact in fp32.
-                        const int X32 = Xb + P.sx[k], Y32 = Yb + P.sy[k];
                         const int li = (Y32 >> 24) * PITCH + (X32 >> 24);
                         const u32 p00 = srct[li], p01 = srct[li + 1], p10 = srct[li + PITCH], p11 = srct[li + PITCH + 1];
                         have = (((p00 ^ p01) | (p10 ^ p11) | (p00 ^ p10)) << 8) != 0;
