@@ -3,6 +3,8 @@ oracle on the same seeded inputs.  Integer / nearest-neighbour ops must be bit-e
 Gaussian and fp32 bilinear are checked on the pre-quantisation fp32 value to 1e-5 relative
 (BASELINE.json north_star) and the uint8 output may differ by 1 only where the oracle's
 float value sits within that tolerance of a rounding/truncation boundary."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -396,3 +398,42 @@ def test_empty_batches_and_degenerate_sizes(device):
     assert np.array_equal(host(ops.rotate(one, 45.0, ops.NEAREST, (9, 9, 9))), O.apply_rotation(synth(70, 1, 1), -45.0)) or True
     a = synth(71, 2, 3)
     assert np.array_equal(host(ops.resize_lanczos(dev(a, device), (5, 4))), O.resize_lanczos(a, (5, 4)))
+
+
+_KNOB_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from imagetransformations_amd import ops
+from oracle import imgxf_oracle as O
+from conftest import synth
+dev = torch.device("cuda:0")
+a = synth(61, 270, 480)                       # 16-byte aligned rows: the fast paths' home turf
+t = torch.from_numpy(a).to(dev)
+h, w = a.shape[:2]
+g, f32 = ops.gaussian_blur(t, 5, 5 / 6, return_f32=True)
+ref = O.gaussian_blur_f64(a, 5, 5 / 6)
+assert (np.abs(f32.cpu().numpy() - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0)).all(), "gaussian"
+m = O.rotate_zoom_matrix(w, h, 30.0, 1.5)
+assert np.array_equal(ops.affine(t, m, (w, h), ops.BILINEAR, (0, 0, 0), precise=True).cpu().numpy(),
+                      O.affine_bilinear(a, (w, h), m, fill=(0, 0, 0))), "bilinear"
+assert np.array_equal(ops.rotate(t, -30.0, ops.NEAREST, (0, 0, 0)).cpu().numpy(), O.apply_rotation(a, 30.0)), "nearest"
+assert np.array_equal(ops.resize_lanczos(t, (int(w * 1.1), int(h * 1.1))).cpu().numpy(),
+                      O.resize_lanczos(a, (int(w * 1.1), int(h * 1.1)))), "lanczos"
+assert np.array_equal(ops.rgb_sobel_magnitude(t).cpu().numpy(), O.rgb_sobel_magnitude(a)), "sobel"
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("knob", ["IMGXF_NO_MARCH", "IMGXF_AFFINE_NO_LDS", "IMGXF_AFFINE_NO_DMA", "IMGXF_LANCZOS_SLOW"])
+def test_general_kernels_behind_the_tuning_knobs(device, knob):
+    """The environment knobs route aligned inputs to the general kernels (LDS-tiled separable
+    filter, global-gather affine, dword-staged nearest, per-tap Lanczos); each must hold the
+    same parity as the fast path it replaces.  One child process per knob (the library reads
+    the knobs once)."""
+    import subprocess, sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **{knob: "1"})
+    code = _KNOB_SCRIPT.format(root=root)
+    out = subprocess.run([_sys.executable, "-c", "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n%s" % (
+        os.path.join(root, "tests"), root, code)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
