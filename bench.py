@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=128, help="4K frames resident per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--scatter-gather", action="store_true",
+                    help="N > 1 only: also time a root<->ranks scatter + gather of 8 frames per rank "
+                         "over RCCL point-to-point (reported separately, never part of `value`)")
     ap.add_argument("--fast-bilinear", action="store_true",
                     help="fp32 interpolation instead of the Pillow-bit-exact fp64 path")
     return ap.parse_args()
@@ -232,10 +235,10 @@ def main():
                                        "roofline_frac": round(GAUSS_BYTES_PER_PX * npx / (t_h * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         result["ops"] = extras
 
-    if world > 1:
+    if world > 1 and args.scatter_gather:
         # separate line: root -> ranks scatter and ranks -> root gather of 8 frames
-        # per rank over RCCL point-to-point, outside the timed region; a failure here must not
-        # cost the headline line
+        # per rank over RCCL point-to-point, outside the timed region.  Opt-in: it has only been
+        # rehearsed with gloo on one GPU, and a stuck transfer must not cost the headline line
         try:
             from imagetransformations_amd import sharding
             nfr = 8 * world
