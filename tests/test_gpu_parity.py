@@ -437,3 +437,45 @@ def test_general_kernels_behind_the_tuning_knobs(device, knob):
     out = subprocess.run([_sys.executable, "-c", "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n%s" % (
         os.path.join(root, "tests"), root, code)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_c_abi_calls_are_stream_capturable(device):
+    """The C-ABI entry points only launch on the stream they are given (no allocation, no
+    synchronisation), so a sequence of them can be captured into a HIP graph and replayed:
+    the launch-bound small-image case (a batch of 32x32 CIFAR frames through blur -> rotate ->
+    brightness) as ONE graph launch."""
+    from imagetransformations_amd import _ffi, ops
+    batch = np.stack([synth(70 + i, 32, 32) for i in range(64)])
+    src = dev(batch, device)
+    a, b, c = torch.empty_like(src), torch.empty_like(src), torch.empty_like(src)
+    m = _ffi.f64_array(ops.rotate_matrix(32, 32, -22.5))
+    fill = _ffi.u8_array([0, 0, 0])
+
+    def chain(stream):
+        _ffi.call("imgxf_gaussian_u8", _ffi.vp(_ffi.view_of(src)), _ffi.vp(_ffi.view_of(a)), 7, 1.0, None, stream)
+        _ffi.call("imgxf_affine_u8", _ffi.vp(_ffi.view_of(a)), _ffi.vp(_ffi.view_of(b)), m, _ffi.FILTER_NEAREST, fill, 1, None, stream)
+        _ffi.call("imgxf_blend_u8", None, fill, _ffi.vp(_ffi.view_of(b)), None, _ffi.vp(_ffi.view_of(c)), 1.05, stream)
+
+    chain(torch.cuda.current_stream().cuda_stream)          # eager reference (also warms the kernels)
+    torch.cuda.synchronize()
+    want = c.clone()
+    c.zero_()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            chain(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert not torch.equal(c, want)                          # capture did not execute
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(c, want)
+    # new input, same graph
+    src.copy_(dev(batch[::-1].copy(), device))
+    g.replay()
+    torch.cuda.synchronize()
+    got = c.clone()
+    assert not torch.equal(got, want)
+    chain(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(got, c)
