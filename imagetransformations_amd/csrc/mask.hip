@@ -6,6 +6,7 @@
 //   this structuring element equals "some set pixel within L1 distance k".
 #include "imgxf_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace imgxf {
 
@@ -88,6 +89,86 @@ __global__ __launch_bounds__(256) void dilate_kernel(View s, View d, int k) {
     }
 }
 
+// ---- binary_dilation(mask, iterations=K) with the cross element, marching form --------------
+// K iterations of the 4-connected cross = "some set pixel within L1 distance K" (border 0):
+//   out(y,x) = OR_{|dy|<=K} hd_{K-|dy|}(y+dy, x),   hd_r(y,x) = OR_{|dx|<=r} m(y, x+dx).
+// A lane owns 16 bytes of a row and marches down the rows of its chunk: every new row yields
+// hd_0..hd_K of its 4 dwords (byte funnel shifts against the neighbouring dwords; the dwords of
+// the neighbouring lanes come over DPP wave shifts) and is OR-ed into the 2K+1 pending output
+// rows held in registers; the oldest one is then complete.  Strips overlap by one lane on each
+// side (lanes 0 and 63 only supply halo bytes).  Any non-zero input byte counts as set.
+__device__ __forceinline__ u32 dpp_from_prev_lane(u32 v) {   // lane i <- lane i-1, lane 0 <- 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u32 dpp_from_next_lane(u32 v) {   // lane i <- lane i+1, lane 63 <- 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void dilate_march_kernel(View s, View d, int rows_per_chunk, int nstrips) {
+    constexpr int NP = 2 * K + 1;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = blockIdx.x * 4 + wave;
+    if (strip >= nstrips) return;                                 // wave-uniform
+    const int f = blockIdx.z;
+    const int y0 = blockIdx.y * rows_per_chunk, y1 = min(s.h, y0 + rows_per_chunk);
+    const int xb = strip * 992 + (lane - 1) * 16;                 // may be -16 or >= w: halo-only / idle lanes
+    const bool inrow = xb >= 0 && xb + 16 <= s.w;
+    const bool writer = inrow && lane >= 1 && lane <= 62;
+    u32 acc[NP][4];
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j][q] = 0;
+
+    // input rows y0-K .. y1+K-1; after consuming row t the output row t-K is complete
+    for (int base = y0 - K; base < y1 + K; base += NP) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int t = base + u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (inrow && t >= 0 && t < s.h && t < y1 + K) v = *(const uint4*)(s.row(f, t) + xb);
+            const u32 c[4] = {v.x, v.y, v.z, v.w};
+            const u32 L = dpp_from_prev_lane(c[3]), R = dpp_from_next_lane(c[0]);
+            u32 hd[K + 1][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32 p = q == 0 ? L : c[q - 1], n = q == 3 ? R : c[q + 1];
+                hd[0][q] = c[q];
+#pragma unroll
+                for (int r = 1; r <= K; ++r)
+                    hd[r][q] = hd[r - 1][q] | __builtin_amdgcn_alignbyte(n, c[q], (u32)r) | __builtin_amdgcn_alignbyte(c[q], p, (u32)(4 - r));
+            }
+            // pending output j (ring position) is |dy| rows away from this input row
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                // ring: output row (t - K) lives at position (u + 1) % NP after this step's store;
+                // position p holds output row  t - K + ((p - (u + 1) + NP) % NP)
+                const int rel = (j - (u + 1) + NP + NP) % NP;         // 0 .. 2K: output row t - K + rel
+                const int dy = rel - K;                                  // input row t is dy below that output... |dy| <= K
+                const int r = K - (dy < 0 ? -dy : dy);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j][q] |= hd[r][q];
+            }
+            // output row t-K (ring position (u+1) % NP) has now seen all of its 2K+1 input rows
+            const int done = (u + 1) % NP;
+            const int yo = t - K;
+            if (writer && yo >= y0 && yo < y1) {
+                u32 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32 x = acc[done][q];
+                    const u32 hi = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;   // bit 7 of every non-zero byte
+                    o[q] = hi | (hi - (hi >> 7));                                           // -> 0xff
+                }
+                *(uint4*)(d.row(f, yo) + xb) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[done][q] = 0;
+        }
+    }
+}
+
 static inline unsigned grid_for(int64_t total) {
     int64_t blocks = (total + 255) / 256;
     return (unsigned)(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks));
@@ -138,8 +219,22 @@ IMGXF_API int imgxf_dilate_cross_u8(const imgxf_view* src, const imgxf_view* dst
     if (!same_geometry(src, dst) || src->c != 1) return IMGXF_ERR_SHAPE;
     if (iterations < 1 || iterations > 16) return IMGXF_ERR_ARG;
     if (empty_view(src)) return IMGXF_OK;
-    const View d = make_view(dst);
+    const View d = make_view(dst), sv = make_view(src);
+    static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
+    if (iterations == 3 && !no_march && d.w % 16 == 0 && d.w >= 64 && d.n <= 65535 &&
+        ((((uintptr_t)sv.p) | (uintptr_t)sv.rs | (uintptr_t)sv.fs | (uintptr_t)d.p | (uintptr_t)d.rs | (uintptr_t)d.fs) & 15) == 0) {
+        const int nstrips = (d.w + 991) / 992;
+        int64_t nchunks = (d.h + 127) / 128;
+        while (nchunks * ((nstrips + 3) / 4) * d.n < 2048 && (d.h + nchunks - 1) / nchunks > 32) nchunks *= 2;
+        const int rpc = (int)((d.h + nchunks - 1) / nchunks);
+        nchunks = (d.h + rpc - 1) / rpc;
+        if (nchunks <= 65535) {
+            hipLaunchKernelGGL((dilate_march_kernel<3>), dim3((unsigned)((nstrips + 3) / 4), (unsigned)nchunks, (unsigned)d.n),
+                               dim3(256), 0, (hipStream_t)stream, sv, d, rpc, nstrips);
+            return launch_status();
+        }
+    }
     hipLaunchKernelGGL(dilate_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0,
-                       (hipStream_t)stream, make_view(src), d, iterations);
+                       (hipStream_t)stream, sv, d, iterations);
     return launch_status();
 }

@@ -479,3 +479,24 @@ def test_c_abi_calls_are_stream_capturable(device):
     chain(torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(got, c)
+
+
+@pytest.mark.parametrize("hw", [(70, 2048), (131, 1008), (33, 64), (300, 3840)])
+def test_dilation_marching_kernel_geometries(device, hw):
+    """3 iterations of the cross on 16-byte aligned widths take the marching kernel: several
+    strips per row, several row chunks, sparse masks (isolated pixels show the diamond), set
+    pixels on every border, and non-0/255 input values (any non-zero byte counts as set)."""
+    from imagetransformations_amd import ops
+    h, w = hw
+    rng = np.random.default_rng(h * 7 + w)
+    m = (rng.random((h, w)) < 0.002)
+    m[0, :: 97] = True; m[-1, 5:: 89] = True; m[:: 53, 0] = True; m[7:: 61, -1] = True
+    if w > 1000:
+        m[h // 2, 985:1000] = True                 # straddles the first strip seam (992)
+    vals = np.where(m, rng.integers(1, 256, (h, w)), 0).astype(np.uint8)
+    want = (O.binary_dilation_cross(m, 3) * 255).astype(np.uint8)
+    got = host(ops.dilate_cross(dev(vals, device), 3))
+    assert np.array_equal(got, want)
+    batch = np.stack([vals, vals[::-1].copy()])
+    got2 = host(ops.dilate_cross(dev(batch[..., None], device), 3))
+    assert np.array_equal(got2[1, ..., 0], (O.binary_dilation_cross(m[::-1], 3) * 255).astype(np.uint8))
