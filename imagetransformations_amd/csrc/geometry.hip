@@ -8,10 +8,15 @@ namespace imgxf {
 
 struct Fill4 { u8 v[4]; };
 
-__global__ __launch_bounds__(256) void fill_kernel(View d, Fill4 col) {
+// The byte pattern of a filled row has period lcm(16, c) = 16 or 48 bytes: the host passes the
+// three 16-byte chunks of one period and the kernel only picks chunk (index % 3)
+struct FillPat { uint4 q[3]; };
+
+__global__ __launch_bounds__(256) void fill_kernel(View d, FillPat pat) {
     const int rowbytes = d.w * d.c;
     const int nchunks = (rowbytes + 15) >> 4;
     const int64_t total = (int64_t)d.n * d.h * nchunks;
+    const bool al = ((((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs) & 15) == 0;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int ck = (int)(t % nchunks);
         const int64_t r = t / nchunks;
@@ -19,16 +24,14 @@ __global__ __launch_bounds__(256) void fill_kernel(View d, Fill4 col) {
         const int xb = ck << 4;
         u8* dp = d.row(f, y) + xb;
         const int nv = min(16, rowbytes - xb);
-        int ch = xb % d.c;
-        u32 o[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const u32 v = ch == 0 ? col.v[0] : ch == 1 ? col.v[1] : ch == 2 ? col.v[2] : col.v[3];
-            o[e >> 2] |= v << (8 * (e & 3));
-            ch = (ch + 1 == d.c) ? 0 : ch + 1;
+        const int ph = ck % 3;
+        const uint4 v = ph == 0 ? pat.q[0] : (ph == 1 ? pat.q[1] : pat.q[2]);
+        if (nv == 16 && al) {
+            *(uint4*)dp = v;
+        } else {
+            const u32 o[4] = {v.x, v.y, v.z, v.w};
+            for (int e = 0; e < nv; ++e) dp[e] = (u8)(o[e >> 2] >> (8 * (e & 3)));
         }
-        if (nv == 16 && (((uintptr_t)dp) & 15) == 0) *(uint4*)dp = make_uint4(o[0], o[1], o[2], o[3]);
-        else for (int e = 0; e < nv; ++e) dp[e] = (u8)(o[e >> 2] >> (8 * (e & 3)));
     }
 }
 
@@ -100,11 +103,13 @@ IMGXF_API int imgxf_fill_u8(const imgxf_view* dst, const uint8_t* color, void* s
     IMGXF_CHECK(check_view(dst));
     if (!color) return IMGXF_ERR_NULL;
     if (empty_view(dst)) return IMGXF_OK;
-    Fill4 c; memset(&c, 0, sizeof(c));
-    for (int j = 0; j < dst->c; ++j) c.v[j] = color[j];
+    FillPat pat;
+    uint8_t bytes[48];
+    for (int i = 0; i < 48; ++i) bytes[i] = color[i % dst->c];     // 48 is a multiple of c = 1..4
+    memcpy(&pat, bytes, sizeof(bytes));
     const View d = make_view(dst);
     const int64_t total = (int64_t)d.n * d.h * ((d.rowbytes() + 15) >> 4);
-    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, d, c);
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, d, pat);
     return launch_status();
 }
 

@@ -11,11 +11,14 @@
 namespace imgxf {
 
 __global__ __launch_bounds__(256) void chist_kernel(View s, u32* hist) {
-    __shared__ u32 h[4 * 256];
+    // 4 sub-histograms per channel (lane & 3 picks one) spread same-bin atomics of neighbouring lanes
+    constexpr int NS = 4;
+    __shared__ u32 h[NS * 4 * 256];
     const int C = s.c;
-    for (int i = threadIdx.x; i < C * 256; i += 256) h[i] = 0;
+    for (int i = threadIdx.x; i < NS * C * 256; i += 256) h[i] = 0;
     __syncthreads();
     const int f = blockIdx.y;
+    u32* hs = h + (threadIdx.x & (NS - 1)) * C * 256;
     const int rowbytes = s.w * C;
     const int64_t total = (int64_t)s.h * rowbytes;
     const bool vec = (rowbytes % 4 == 0) && ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 3) == 0;
@@ -28,19 +31,23 @@ __global__ __launch_bounds__(256) void chist_kernel(View s, u32* hist) {
             int ch = (xw * 4) % C;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                atomicAdd(&h[ch * 256 + ((v >> (8 * b)) & 0xffu)], 1u);
+                atomicAdd(&hs[ch * 256 + ((v >> (8 * b)) & 0xffu)], 1u);
                 ch = ch + 1 == C ? 0 : ch + 1;
             }
         }
     } else {
         for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
             const int xb = (int)(t % rowbytes), y = (int)(t / rowbytes);
-            atomicAdd(&h[(xb % C) * 256 + s.row(f, y)[xb]], 1u);
+            atomicAdd(&hs[(xb % C) * 256 + s.row(f, y)[xb]], 1u);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C * 256; i += 256)
-        if (h[i]) atomicAdd(&hist[(int64_t)f * C * 256 + i], h[i]);
+    for (int i = threadIdx.x; i < C * 256; i += 256) {
+        u32 sum = 0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) sum += h[k * C * 256 + i];
+        if (sum) atomicAdd(&hist[(int64_t)f * C * 256 + i], sum);
+    }
 }
 
 // PIL/ImageOps.py equalize(): histo = non-zero bins; step = (sum(histo) - histo[-1]) // 255;

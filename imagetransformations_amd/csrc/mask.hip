@@ -11,17 +11,37 @@
 namespace imgxf {
 
 __global__ __launch_bounds__(256) void hist_kernel(View s, u32* hist) {
-    __shared__ u32 h[256];
-    h[threadIdx.x] = 0;
+    // 8 sub-histograms (lane & 7 picks one) keep same-bin LDS atomics of neighbouring lanes apart;
+    // rows are read as dwords when the view allows it
+    __shared__ u32 h[8][256];
+    for (int i = threadIdx.x; i < 8 * 256; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
     const int f = blockIdx.y;
-    const int64_t total = (int64_t)s.h * s.w;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-        const int x = (int)(t % s.w), y = (int)(t / s.w);
-        atomicAdd(&h[s.row(f, y)[x]], 1u);
+    u32* hs = h[threadIdx.x & 7];
+    const bool vec = (s.w % 4 == 0) && ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 3) == 0;
+    if (vec) {
+        const int rowwords = s.w >> 2;
+        const int64_t words = (int64_t)s.h * rowwords;
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < words; t += (int64_t)gridDim.x * 256) {
+            const int xw = (int)(t % rowwords), y = (int)(t / rowwords);
+            const u32 v = ((const u32*)s.row(f, y))[xw];
+            atomicAdd(&hs[v & 0xffu], 1u);
+            atomicAdd(&hs[(v >> 8) & 0xffu], 1u);
+            atomicAdd(&hs[(v >> 16) & 0xffu], 1u);
+            atomicAdd(&hs[v >> 24], 1u);
+        }
+    } else {
+        const int64_t total = (int64_t)s.h * s.w;
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+            const int x = (int)(t % s.w), y = (int)(t / s.w);
+            atomicAdd(&hs[s.row(f, y)[x]], 1u);
+        }
     }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[f * 256 + threadIdx.x], h[threadIdx.x]);
+    u32 sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += h[k][threadIdx.x];
+    if (sum) atomicAdd(&hist[f * 256 + threadIdx.x], sum);
 }
 
 // numpy percentile, method 'linear' (lib/_function_base_impl.py: _compute_virtual_index with
@@ -59,6 +79,26 @@ __global__ void percentile_kernel(const u32* hist, int nframes, int64_t count, d
 }
 
 __global__ __launch_bounds__(256) void gt_mask_kernel(View s, View d, const double* thr) {
+    // (double)e > thr  <=>  e > floor(thr) for integer e: compare bytes against an integer limit
+    const bool vec = (d.w % 4 == 0) &&
+                     ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | (uintptr_t)d.p | (uintptr_t)d.rs | (uintptr_t)d.fs) & 3) == 0;
+    if (vec) {
+        const int rowwords = d.w >> 2;
+        const int64_t total = (int64_t)d.n * d.h * rowwords;
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+            const int xw = (int)(t % rowwords);
+            const int64_t r = t / rowwords;
+            const int y = (int)(r % d.h), f = (int)(r / d.h);
+            const double th = thr[f];
+            const int lim = th < 0.0 ? -1 : (th >= 255.0 ? 255 : (int)floor(th));   // e > lim
+            const u32 v = ((const u32*)s.row(f, y))[xw];
+            u32 o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) o |= ((int)((v >> (8 * b)) & 0xffu) > lim ? 0xffu : 0u) << (8 * b);
+            ((u32*)d.row(f, y))[xw] = o;
+        }
+        return;
+    }
     const int64_t total = (int64_t)d.n * d.h * d.w;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int x = (int)(t % d.w);
@@ -207,7 +247,7 @@ IMGXF_API int imgxf_percentile_mask_u8(const imgxf_view* src, const uint32_t* hi
     hipLaunchKernelGGL(percentile_kernel, dim3((unsigned)((src->n + 63) / 64)), dim3(64), 0, st, hist,
                        src->n, (int64_t)src->h * src->w, q, thr_out);
     const View d = make_view(dst);
-    hipLaunchKernelGGL(gt_mask_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0, st,
+    hipLaunchKernelGGL(gt_mask_kernel, dim3(grid_for((int64_t)d.n * d.h * ((d.w + 3) / 4))), dim3(256), 0, st,
                        make_view(src), d, (const double*)thr_out);
     return launch_status();
 }

@@ -222,6 +222,49 @@ __global__ __launch_bounds__(256) void permute_kernel(View s, View d, Perm4 pm) 
 }
 
 // ---------------- composite: mask ? im1 : im2 ----------------
+// Image.composite(im1, im2, mask) for the 0/255 masks the reference builds
+// (/root/reference/transformation.py:343-344); any non-zero mask byte selects im1.
+__device__ __forceinline__ u32 nonzero_bytes_to_ff(u32 x) {
+    const u32 hi = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;   // bit 7 of every non-zero byte
+    return hi | (hi - (hi >> 7));
+}
+
+// RGB fast path: a lane owns 16 pixels = 48 bytes of both images and 16 mask bytes; each mask
+// dword (4 pixels) is spread over 3 image dwords with v_perm_b32 and selects with v_bfi_b32
+__global__ __launch_bounds__(256) void composite_rgb16_kernel(View a, View b, View m, View d) {
+    const int ngrp = d.w >> 4;
+    const int64_t total = (int64_t)d.n * d.h * ngrp;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int g = (int)(t % ngrp);
+        const int64_t r = t / ngrp;
+        const int y = (int)(r % d.h), f = (int)(r / d.h);
+        const uint4 mq = *(const uint4*)(m.row(f, y) + g * 16);
+        const u32 mw[4] = {mq.x, mq.y, mq.z, mq.w};
+        const uint4* ap = (const uint4*)(a.row(f, y) + g * 48);
+        const uint4* bp = (const uint4*)(b.row(f, y) + g * 48);
+        uint4* dp = (uint4*)(d.row(f, y) + g * 48);
+        u32 av[12], bv[12], ov[12];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint4 qa = ap[k], qb = bp[k];
+            av[4 * k] = qa.x; av[4 * k + 1] = qa.y; av[4 * k + 2] = qa.z; av[4 * k + 3] = qa.w;
+            bv[4 * k] = qb.x; bv[4 * k + 1] = qb.y; bv[4 * k + 2] = qb.z; bv[4 * k + 3] = qb.w;
+        }
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {                       // 4 pixels -> 3 dwords
+            const u32 mm = nonzero_bytes_to_ff(mw[p4]);
+            const u32 s0 = __builtin_amdgcn_perm(0, mm, 0x01000000u);   // bytes of pixels 0,0,0,1
+            const u32 s1 = __builtin_amdgcn_perm(0, mm, 0x02020101u);   // 1,1,2,2
+            const u32 s2 = __builtin_amdgcn_perm(0, mm, 0x03030302u);   // 2,3,3,3
+            ov[3 * p4] = (av[3 * p4] & s0) | (bv[3 * p4] & ~s0);
+            ov[3 * p4 + 1] = (av[3 * p4 + 1] & s1) | (bv[3 * p4 + 1] & ~s1);
+            ov[3 * p4 + 2] = (av[3 * p4 + 2] & s2) | (bv[3 * p4 + 2] & ~s2);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dp[k] = make_uint4(ov[4 * k], ov[4 * k + 1], ov[4 * k + 2], ov[4 * k + 3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void composite_kernel(View a, View b, View m, View d) {
     const int64_t total = (int64_t)d.n * d.h * d.w;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -496,8 +539,15 @@ IMGXF_API int imgxf_composite_u8(const imgxf_view* im1, const imgxf_view* im2,
         return IMGXF_ERR_SHAPE;
     if (empty_view(dst)) return IMGXF_OK;
     const View d = make_view(dst);
+    const View va = make_view(im1), vb = make_view(im2), vm = make_view(mask);
+    auto al16 = [](const View& v) { return ((((uintptr_t)v.p) | (uintptr_t)v.rs | (uintptr_t)v.fs) & 15) == 0; };
+    if (d.c == 3 && d.w % 16 == 0 && al16(va) && al16(vb) && al16(vm) && al16(d)) {
+        hipLaunchKernelGGL(composite_rgb16_kernel, dim3(grid_for((int64_t)d.n * d.h * (d.w >> 4))), dim3(256), 0,
+                           (hipStream_t)stream, va, vb, vm, d);
+        return launch_status();
+    }
     hipLaunchKernelGGL(composite_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0,
-                       (hipStream_t)stream, make_view(im1), make_view(im2), make_view(mask), d);
+                       (hipStream_t)stream, va, vb, vm, d);
     return launch_status();
 }
 
