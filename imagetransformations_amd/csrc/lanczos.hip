@@ -6,6 +6,7 @@
 #include <math.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include <stdlib.h>
 
 #define PRECISION_BITS (32 - 8 - 2)
@@ -20,6 +21,7 @@ struct imgxf_lanczos_plan {
     // window-normalised copies for the fast kernels: every window is KP samples wide and lies
     // fully inside the source (start = min(xmin, in - KP)), coefficients shifted accordingly
     int kpx, kpy;            // padded window widths (kpx in {8,12,16}; 0 = fast kernel not usable)
+    int hspan;               // max over 1024-column groups of the 16-B aligned source byte span (+16), 0 = unknown
     int* d_start_x;          // [out_w]
     int* d_pk_x;             // [out_w][kpx]
     int* d_start_y;          // [out_h]
@@ -31,6 +33,8 @@ struct imgxf_lanczos_plan {
 namespace imgxf {
 
 typedef uint32_t u32_ua __attribute__((aligned(1)));
+typedef uint32_t u32x2_ua __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t u32x4_ua __attribute__((ext_vector_type(4), aligned(1)));
 
 static inline double sinc_filter(double x) {
     if (x == 0.0) return 1.0;
@@ -129,6 +133,10 @@ static void build_padded(int in_size, int out_size, int ksize, int KP, const std
     }
 }
 
+// pixel (8 bits) x 22-bit coefficient: the 24-bit multiplier runs at full rate, a 32-bit
+// v_mul_lo_u32 at a quarter of it (the compiler cannot see the coefficient's range)
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+
 __device__ __forceinline__ u8 clip8(int v) {
     v >>= PRECISION_BITS;
     // keep the shift and the clamp apart: hipcc (ROCm 7.2) otherwise fuses pairs of them into
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256) void resample_h_kernel(View s, View d, const i
         for (int x = 0; x < cnt; ++x) {
             const int w = k[x];
 #pragma unroll
-            for (int j = 0; j < C; ++j) acc[j] += (int)sp[x * C + j] * w;
+            for (int j = 0; j < C; ++j) acc[j] += mul24((int)sp[x * C + j], w);
         }
         u8* dp = d.row(f, y) + xx * C;
 #pragma unroll
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(256) void resample_v_kernel(View s, View d, const i
         const int* k = kk + (int64_t)yy * ksize;
         int acc = 1 << (PRECISION_BITS - 1);
         const u8* sp = s.row(f, ymin) + xb;
-        for (int y = 0; y < cnt; ++y) acc += (int)sp[(int64_t)y * s.rs] * k[y];
+        for (int y = 0; y < cnt; ++y) acc += mul24((int)sp[(int64_t)y * s.rs], k[y]);
         d.row(f, yy)[xb] = clip8(acc);
     }
 }
@@ -213,8 +221,19 @@ __global__ __launch_bounds__(256) void resample_h_fast_kernel(View s, View d, co
         for (int j = 0; j < 4; ++j) {
             u32 w[ND];
             const u8* wp = rowp + st[j];
+            // widest loads that tile the window exactly (byte-aligned addresses are fine for
+            // global loads): 24 B = x4 + x2, 36 B = 2 x4 + x1, 48 B = 3 x4.  The L1 address path
+            // charges per wave-level load instruction, so 2-3 wide loads beat 6-12 dword loads.
 #pragma unroll
-            for (int q = 0; q < ND; ++q) w[q] = *(const u32_ua*)(wp + 4 * q);
+            for (int q = 0; q + 4 <= ND; q += 4) {
+                const u32x4_ua v = *(const u32x4_ua*)(wp + 4 * q);
+                w[q] = v.x; w[q + 1] = v.y; w[q + 2] = v.z; w[q + 3] = v.w;
+            }
+            if constexpr (ND % 4 >= 2) {
+                const u32x2_ua v = *(const u32x2_ua*)(wp + 4 * (ND & ~3));
+                w[ND & ~3] = v.x; w[(ND & ~3) + 1] = v.y;
+            }
+            if constexpr (ND % 2 == 1) w[ND - 1] = *(const u32_ua*)(wp + 4 * (ND - 1));
             int acc[C];
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) acc[ch] = 1 << (PRECISION_BITS - 1);
@@ -223,7 +242,7 @@ __global__ __launch_bounds__(256) void resample_h_fast_kernel(View s, View d, co
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
                     const int b = t * C + ch;
-                    acc[ch] += (int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu) * kc[j][t];
+                    acc[ch] += mul24((int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu), kc[j][t]);
                 }
             }
 #pragma unroll
@@ -240,6 +259,110 @@ __global__ __launch_bounds__(256) void resample_h_fast_kernel(View s, View d, co
 #pragma unroll
                 for (int k = 0; k < 4 * C; ++k) if (k == e) v = out[k];
                 dp[e] = (u8)v;
+            }
+        }
+    }
+}
+
+// ---- horizontal pass through LDS (RGB, 16-byte aligned source rows).  PMC on the kernel above:
+// the four windows of a lane overlap almost completely and neighbouring lanes' windows do too,
+// so a wave requests ~6 KiB per row to use ~0.7 KiB of it, and the L1 address path is charged per
+// lane request (~58 TCP accesses per wave-level x4 load, TCP 80 % busy, VALU 31 %).  Here the
+// workgroup copies the byte span its 1024 output columns need into LDS once per row with
+// coalesced 16-byte loads (next row's chunks are in flight while the current row is filtered;
+// two LDS buffers, one barrier per row), and every window is read from LDS as aligned dwords
+// plus a funnel shift.
+template <int KP>
+__global__ __launch_bounds__(256) void resample_h_lds_kernel(View s, View d, const int* start, const int* pk,
+                                                             int rows_per_block, int bufbytes) {
+    constexpr int C = 3, ND = KP * 3 / 4, MAXCH = 2;         // <= 2 chunks of 16 B per lane and row
+    extern __shared__ __attribute__((aligned(16))) u8 hbuf[];  // 2 x bufbytes
+    const int tid = threadIdx.x;
+    const int x_first = blockIdx.x * 1024;
+    const int x0 = x_first + tid * 4;
+    const int f = blockIdx.z;
+    const int y_begin = blockIdx.y * rows_per_block, y_end = min(d.h, y_begin + rows_per_block);
+    const int x_last = min(x_first + 1023, d.w - 1);
+    // byte span of the source row this workgroup needs, from a 16-byte aligned base
+    const int base = (start[x_first] * C) & ~15;
+    const int span_end = (start[x_last] + KP) * C;             // exclusive; <= row bytes (start-clamped tables)
+    const int nchunks = (span_end - base + 15) >> 4;           // <= bufbytes / 16 (host-checked)
+    const int rowbytes = s.w * C;
+
+    const bool live = x0 < d.w;
+    int so[4], sr[4];                                          // window offset in the buffer: dword index, byte shift
+    int kc[4][KP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xx = min(x0 + j, d.w - 1);
+        const int o = start[xx] * C - base;
+        so[j] = o & ~3; sr[j] = o & 3;
+#pragma unroll
+        for (int t = 0; t < KP; ++t) kc[j][t] = pk[(int64_t)xx * KP + t];
+    }
+    const int npx = min(4, d.w - x0);
+
+    uint4 pre[MAXCH];
+    auto fetch = [&](int y) {
+        const u8* rowp = s.row(f, y) + base;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const int ck = tid + 256 * c;
+            pre[c] = make_uint4(0, 0, 0, 0);
+            if (ck < nchunks && base + 16 * ck + 16 <= rowbytes) pre[c] = *(const uint4*)(rowp + 16 * ck);
+        }
+    };
+    auto deposit = [&](u8* buf) {
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const int ck = tid + 256 * c;
+            if (ck < nchunks) *(uint4*)(buf + 16 * ck) = pre[c];
+        }
+    };
+
+    if (y_begin < y_end) fetch(y_begin);
+    for (int y = y_begin; y < y_end; ++y) {
+        u8* buf = hbuf + ((y - y_begin) & 1) * bufbytes;
+        deposit(buf);
+        __syncthreads();
+        if (y + 1 < y_end) fetch(y + 1);                       // lands while this row is filtered
+        if (live) {
+            u32 out[4 * C];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32 raw[ND + 1];
+                const u32* wp = (const u32*)(buf + so[j]);
+#pragma unroll
+                for (int q = 0; q <= ND; ++q) raw[q] = wp[q];
+                u32 w[ND];
+#pragma unroll
+                for (int q = 0; q < ND; ++q) w[q] = __builtin_amdgcn_alignbyte(raw[q + 1], raw[q], (u32)sr[j]);
+                int acc[C];
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) acc[ch] = 1 << (PRECISION_BITS - 1);
+#pragma unroll
+                for (int t = 0; t < KP; ++t) {
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch) {
+                        const int b = t * C + ch;
+                        acc[ch] += mul24((int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu), kc[j][t]);
+                    }
+                }
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) out[j * C + ch] = clip8(acc[ch]);
+            }
+            u8* dp = d.row(f, y) + x0 * C;
+            if (npx == 4 && (((uintptr_t)dp) & 3) == 0) {
+#pragma unroll
+                for (int q = 0; q < C; ++q)
+                    ((u32*)dp)[q] = out[4 * q] | (out[4 * q + 1] << 8) | (out[4 * q + 2] << 16) | (out[4 * q + 3] << 24);
+            } else {
+                for (int e = 0; e < npx * C; ++e) {
+                    u32 v = 0;
+#pragma unroll
+                    for (int k = 0; k < 4 * C; ++k) if (k == e) v = out[k];
+                    dp[e] = (u8)v;
+                }
             }
         }
     }
@@ -266,7 +389,7 @@ __global__ __launch_bounds__(256) void resample_v_fast_kernel(View s, View d, co
             const uint4 q = *(const uint4*)(sp + (int64_t)t * s.rs);
             const u32 w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] += (int)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) * c;
+            for (int e = 0; e < 16; ++e) acc[e] += mul24((int)((w[e >> 2] >> (8 * (e & 3))) & 0xffu), c);
         }
     }
     u32 o[4] = {0, 0, 0, 0};
@@ -283,6 +406,18 @@ static inline unsigned grid_for(int64_t total) {
 static int launch_h_fast(const imgxf_lanczos_plan* p, const View& s, const View& d, hipStream_t st) {
     const int rpb = 32;
     dim3 grid((unsigned)((d.w + 1023) / 1024), (unsigned)((d.h + rpb - 1) / rpb), (unsigned)d.n);
+    static const bool no_lds = getenv("IMGXF_LANCZOS_NO_LDS") != nullptr;
+    const bool aligned = ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 15) == 0 && (s.w * 3) % 16 == 0;
+    if (!no_lds && aligned && p->hspan > 0 && p->hspan <= 8192) {
+        const int bufbytes = (p->hspan + 15) & ~15;
+        const size_t lds = 2 * (size_t)bufbytes;
+        switch (p->kpx) {
+            case 8: hipLaunchKernelGGL((resample_h_lds_kernel<8>), grid, dim3(256), lds, st, s, d, p->d_start_x, p->d_pk_x, rpb, bufbytes); break;
+            case 12: hipLaunchKernelGGL((resample_h_lds_kernel<12>), grid, dim3(256), lds, st, s, d, p->d_start_x, p->d_pk_x, rpb, bufbytes); break;
+            default: hipLaunchKernelGGL((resample_h_lds_kernel<16>), grid, dim3(256), lds, st, s, d, p->d_start_x, p->d_pk_x, rpb, bufbytes); break;
+        }
+        return launch_status();
+    }
     switch (p->kpx) {
         case 8: hipLaunchKernelGGL((resample_h_fast_kernel<8>), grid, dim3(256), 0, st, s, d, p->d_start_x, p->d_pk_x, rpb); break;
         case 12: hipLaunchKernelGGL((resample_h_fast_kernel<12>), grid, dim3(256), 0, st, s, d, p->d_start_x, p->d_pk_x, rpb); break;
@@ -352,6 +487,15 @@ IMGXF_API int imgxf_resample_plan_create(imgxf_lanczos_plan** plan, int in_h, in
             std::vector<int> st, pk;
             build_padded(in_w, out_w, p->ksx, kp, b, k, st, pk);
             p->kpx = kp;
+            // source byte span of every group of 1024 output columns (what resample_h_lds_kernel stages);
+            // + 4: the window reader fetches one dword past the window for the funnel shift
+            int span = 0;
+            for (int x0 = 0; x0 < out_w; x0 += 1024) {
+                const int x1 = std::min(x0 + 1023, out_w - 1);
+                const int base = (st[x0] * 3) & ~15;
+                span = std::max(span, (st[x1] + kp) * 3 - base + 4);
+            }
+            p->hspan = span;
             if ((rc = upload(st, &p->d_start_x)) == IMGXF_OK) rc = upload(pk, &p->d_pk_x);
         }
     }
