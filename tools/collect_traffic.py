@@ -8,7 +8,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if "sepconv" in row["Kernel_Name"] and row["Counter_Name"] in vals:
             vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
-rec = {"frames_per_gpu": frames, "kernel": "sepconv_march_kernel<3,2,6>",
+rec = {"frames_per_gpu": frames, "kernel": "sepconv_march_kernel<3,2>",
        "FETCH_SIZE_KiB": sum(vals["FETCH_SIZE"]) / max(1, len(vals["FETCH_SIZE"])),
        "WRITE_SIZE_KiB": sum(vals["WRITE_SIZE"]) / max(1, len(vals["WRITE_SIZE"])),
        "launches": [len(vals["FETCH_SIZE"]), len(vals["WRITE_SIZE"])],
