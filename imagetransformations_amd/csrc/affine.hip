@@ -931,6 +931,127 @@ __global__ __launch_bounds__(256) void affine_nearest_dma_kernel(View s, View d,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// BICUBIC horizontal-only (apply_shear, /root/reference/transformation.py:212-226: matrix
+// (1, sh, -shift, 0, 1, 0), white fill): m3 == 0, m4 == 1, m5 integral, so the source row is
+// y + m5 exactly and only libImaging's row cubic  p1 + d(p2 + d(p3 + d p4))  is evaluated.
+// The generic kernel does that in fp64 from 12 byte loads per pixel (VALU-bound on fp64).  Here:
+// coordinates stay in un-contracted fp64 (floor / bounds must agree with libImaging), the four
+// taps of a pixel are one 12-byte load, and the cubic runs in fp32 — p2, p3, p4 are exact
+// (integers <= 1020), the three Horner FMAs and d's rounding give |fp32 - fp64| <= 1.5e-4 +
+// 5600 * 2^-25 = 3.2e-4.  PRECISE: a value within GUARD = 4e-4 of an integer (the only place
+// where truncation / the 0 and 255 clamps can differ) is re-evaluated with libImaging's fp64
+// sequence; so are pixels whose taps touch the left / right image border (clamped taps).
+// ---------------------------------------------------------------------------------------
+typedef uint32_t u32x2_sh __attribute__((ext_vector_type(2), aligned(1)));
+
+template <bool PRECISE>
+__global__ __launch_bounds__(256) void shear_bicubic_kernel(View s, View d, AffineParams P) {
+    constexpr int C = 3;
+    constexpr float GUARD = 4.0e-4f;
+    const int lane = threadIdx.x & 63;
+    const int xg = blockIdx.x * 64 + lane;          // group of 4 output pixels
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.z;
+    const int x0 = xg * 4;
+    if (y >= d.h || x0 >= d.w) return;
+    const u8* sp = s.p + (int64_t)f * s.fs;
+    const double yc = (double)y + 0.5;
+    const double a1y = __dmul_rn(P.m[1], yc);
+    // yin = m3*xc + m4*yc + m5 = yc + m5 exactly (host-checked m3 == 0, m4 == 1, m5 integral)
+    const double yin = __dadd_rn(yc, P.m[5]);
+    const bool yok = yin >= 0.0 && yin < (double)s.h;
+    const int yi = (int)floor(yin - 0.5);
+    const u8* row = sp + (int64_t)clampi(yi, 0, s.h - 1) * s.rs;
+
+    auto exact_px = [&](int x, u8 (&px)[C]) {
+        const double xc = (double)x + 0.5;
+        double xin = __dadd_rn(__dadd_rn(__dmul_rn(P.m[0], xc), a1y), P.m[2]);
+        if (!(yok && xin >= 0.0 && xin < (double)s.w)) {
+#pragma unroll
+            for (int j = 0; j < C; ++j) px[j] = P.fill[j];
+            return;
+        }
+        xin -= 0.5;
+        const double xfl = floor(xin);
+        const int xi = (int)xfl;
+        const double dx = xin - xfl;
+        int xs[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xs[t] = clampi(xi - 1 + t, 0, s.w - 1) * C;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const double v = cubic<PreciseArith>((double)row[xs[0] + j], (double)row[xs[1] + j],
+                                                 (double)row[xs[2] + j], (double)row[xs[3] + j], dx);
+            px[j] = v <= 0.0 ? (u8)0 : (v >= 255.0 ? (u8)255 : (u8)(int)v);
+        }
+    };
+
+    u32 od[C] = {0u, 0u, 0u};
+    u32 need = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x0 + k;
+        const double xc = (double)x + 0.5;
+        const double xin = __dadd_rn(__dadd_rn(__dmul_rn(P.m[0], xc), a1y), P.m[2]);
+        const bool ok = yok && xin >= 0.0 && xin < (double)s.w;
+        const double xs = xin - 0.5, xfl = floor(xs);
+        const int xi = (int)xfl;
+        const float dx = (float)(xs - xfl);
+        const bool inner = ok && xi >= 1 && xi + 2 <= s.w - 1;      // all four taps unclamped
+        // taps xi-1 .. xi+2: 12 contiguous bytes (a safe address when the pixel is not `inner`)
+        const u8* tp = row + (inner ? (xi - 1) * C : 0);
+        const u32x2_sh t2 = *(const u32x2_sh*)tp;                   // exactly 12 bytes: x2 + x1
+        const u32 w0 = t2.x, w1 = t2.y, w2 = *(const u32_unaligned*)(tp + 8);
+        float v[C];
+        float dist = 0.0f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            // tap t, channel j = byte 3t + j of the 12
+            const float v1 = (float)((w0 >> (8 * j)) & 0xffu);
+            const float v2 = (float)((j < 1 ? (w0 >> 24) : (w1 >> (8 * (j - 1)))) & 0xffu);
+            const float v3 = (float)((j < 2 ? (w1 >> (8 * (j + 2))) : w2) & 0xffu);
+            const float v4 = (float)((w2 >> (8 * (j + 1))) & 0xffu);
+            const float p2 = v3 - v1;
+            const float p3 = fmaf(2.0f, v1 - v2, v3) - v4;
+            const float p4 = (v2 - v1) + (v4 - v3);
+            v[j] = fmaf(dx, fmaf(dx, fmaf(dx, p4, p3), p2), v2);
+            const float fl = floorf(v[j]);
+            od[(k * C + j) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(fl, (k * C + j) & 3, od[(k * C + j) >> 2]);   // saturates: <=0 -> 0, >=255 -> 255
+            if (PRECISE) dist = fmaxf(dist, fabsf((v[j] - fl) - 0.5f));
+        }
+        const bool flag = !inner || (PRECISE && dist > 0.5f - GUARD);
+        need |= flag ? 1u << k : 0u;
+    }
+    if (need) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((need >> k) & 1u) {
+                u8 px[C];
+                exact_px(x0 + k, px);
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    const int q = (k * C + j) >> 2, sh = ((k * C + j) & 3) * 8;
+                    od[q] = (od[q] & ~(0xffu << sh)) | ((u32)px[j] << sh);
+                }
+            }
+        }
+    }
+    u8* dp = d.row(f, y) + x0 * C;
+    const int npx = min(4, d.w - x0);
+    if (npx == 4 && ((((uintptr_t)dp) & 3) == 0)) {
+#pragma unroll
+        for (int q = 0; q < C; ++q) ((u32*)dp)[q] = od[q];
+    } else {
+        for (int e = 0; e < npx * C; ++e) {
+            u32 vv = 0;
+#pragma unroll
+            for (int q = 0; q < C; ++q) if (q == (e >> 2)) vv = od[q];
+            dp[e] = (u8)(vv >> (8 * (e & 3)));
+        }
+    }
+}
+
 static inline int fix16(double v) {
     const double t = v * 65536.0 + 0.5;
     return t < 0.0 ? (int)floor(t) : (int)t;   // libImaging FLOOR()
@@ -1082,6 +1203,16 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
             if (pr) IMGXF_BIL(1, true, 8, 2); else IMGXF_BIL(1, false, 8, 2);
         }
 #undef IMGXF_BIL
+    }
+    {
+        static const bool no_shear = getenv("IMGXF_AFFINE_NO_SHEAR_FAST") != nullptr;
+        const bool honly = m[3] == 0.0 && m[4] == 1.0 && m[5] == floor(m[5]) && fabs(m[5]) < 1.0e9;
+        if (filter == IMGXF_FILTER_BICUBIC && honly && src->c == 3 && !dbg.p && !no_shear && src->w >= 4) {
+            dim3 block(256), grid((unsigned)((d.w + 255) / 256), (unsigned)((d.h + 3) / 4), (unsigned)d.n);
+            if (pr) hipLaunchKernelGGL((shear_bicubic_kernel<true>), grid, block, 0, st, s, d, P);
+            else hipLaunchKernelGGL((shear_bicubic_kernel<false>), grid, block, 0, st, s, d, P);
+            return launch_status();
+        }
     }
     switch (src->c) {
         case 1: return pr ? launch_affine_filter<1, PreciseArith>(filter, s, d, P, dbg, st)
