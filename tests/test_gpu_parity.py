@@ -500,3 +500,40 @@ def test_dilation_marching_kernel_geometries(device, hw):
     batch = np.stack([vals, vals[::-1].copy()])
     got2 = host(ops.dilate_cross(dev(batch[..., None], device), 3))
     assert np.array_equal(got2[1, ..., 0], (O.binary_dilation_cross(m[::-1], 3) * 255).astype(np.uint8))
+
+
+def test_new_entry_points_reject_bad_arguments(device):
+    """Error behaviour of the widened C-ABI: shape / argument errors surface as ValueError (as
+    Pillow / NumPy raise them), resource errors as ImgxfError; nothing is written on failure."""
+    from imagetransformations_amd import _ffi, ops
+    t = dev(synth(80, 16, 24), device)
+    out = torch.zeros_like(t)
+    st = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(ValueError):
+        ops.lut(t, list(range(100)))                                   # table size
+    with pytest.raises(ValueError):
+        ops.resize(t, (8, 8), resample=0)                              # NEAREST is not a Resample.c filter
+    with pytest.raises(ValueError):
+        ops.resize(t, (0, 8))
+    with pytest.raises(ValueError):
+        _ffi.call("imgxf_flip_u8", _ffi.vp(_ffi.view_of(t)), _ffi.vp(_ffi.view_of(out)), 2, st)       # mode
+    with pytest.raises(ValueError):
+        _ffi.call("imgxf_flip_u8", _ffi.vp(_ffi.view_of(t)), _ffi.vp(_ffi.view_of(out[:8])), 0, st)   # geometry
+    ws = torch.empty(64, dtype=torch.int32, device=device)
+    with pytest.raises(_ffi.ImgxfError):
+        _ffi.call("imgxf_equalize_u8", _ffi.vp(_ffi.view_of(t)), _ffi.vp(_ffi.view_of(out)), ws.data_ptr(), ws.numel() * 4, st)
+    with pytest.raises(ValueError):
+        _ffi.call("imgxf_equalize_u8", _ffi.vp(_ffi.view_of(t)), _ffi.vp(_ffi.view_of(out)), None, 0, st)   # NULL workspace
+    with pytest.raises(ValueError):
+        ops.add_noise_f64(t, torch.zeros(t.shape, dtype=torch.float32, device=device))               # dtype
+    with pytest.raises(ValueError):
+        ops.impulse_noise(t, torch.zeros((16, 25), dtype=torch.float64, device=device), 0.1, 0.9)     # mask shape
+    with pytest.raises(ValueError):
+        _ffi.call("imgxf_shot_noise_u8", _ffi.vp(_ffi.view_of(torch.zeros(t.shape, dtype=torch.float64, device=device))),
+                  0.0, _ffi.vp(_ffi.view_of(out)), st)                                              # lambda must be > 0
+    torch.cuda.synchronize()
+    assert int(out.sum()) == 0
+    # empty batches are fine everywhere
+    e = t[:0]
+    assert ops.lut(e.reshape(0, 24, 3), list(range(256))).numel() == 0
+    assert ops.flip(torch.empty((0, 16, 24, 3), dtype=torch.uint8, device=device)).shape[0] == 0
