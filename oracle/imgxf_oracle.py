@@ -22,7 +22,13 @@ Pinning status (see DESIGN.md "Oracle"):
     BORDER_REFLECT_101, saturate_cast round-half-even, convertScaleAbs = sat(|a*p+b|)).
     Real cv2 uses 8-bit fixed-point kernels for uint8 images, so +-1 LSB residuals
     against a real cv2 build are expected; the contract (BASELINE.json north_star) is
-    the float definition to 1e-5 relative.
+    the float definition to 1e-5 relative.  What does exist for them is the reference
+    pipeline's own JPEG output for given parameters: tests/test_reference_outputs.py checks
+    every apply_* (these three included) against those files up to JPEG noise.
+  * Later additions (ImageFilter box / Gaussian blur and 3x3 kernels, ImageEnhance.*,
+    ImageOps.posterize / solarize / equalize, every Resample.c filter, flips, the Pool's
+    NumPy noise expressions, the entropy feature): PINNED against Pillow / NumPy / SciPy
+    in tests/test_oracle_vs_libs.py.
 
 All image arrays are HWC (or HW) uint8, C-contiguous, RGB order — exactly what
 `np.array(pil_image)` yields at `transformation.py:204,229,273`.
