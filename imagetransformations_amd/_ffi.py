@@ -66,6 +66,9 @@ SIGNATURES = {
     "imgxf_lut_u8": [_VP, _VP, _U8, C.c_void_p],
     "imgxf_equalize_u8": [_VP, _VP, C.c_void_p, C.c_size_t, C.c_void_p],
     "imgxf_channel_histogram_u8": [_VP, C.c_void_p, C.c_void_p],
+    "imgxf_rgb2yuv_u8": [_VP, _VP, C.c_void_p],
+    "imgxf_yuv2rgb_u8": [_VP, _VP, C.c_void_p],
+    "imgxf_equalize_hist_cv_u8": [_VP, _VP, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p],
     "imgxf_box_blur_u8": [_VP, _VP, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p],
     "imgxf_gaussian_blur_pil_u8": [_VP, _VP, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p],
     "imgxf_filter3x3_u8": [_VP, _VP, _F, C.c_float, C.c_float, C.c_void_p],

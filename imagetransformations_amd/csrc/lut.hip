@@ -175,3 +175,15 @@ IMGXF_API int imgxf_equalize_u8(const imgxf_view* src, const imgxf_view* dst, vo
                        s, d, (const u8*)lut, arg);
     return launch_status();
 }
+
+// internal (not in imgxf.h): table apply with per-frame device tables [n][c][256]
+extern "C" __attribute__((visibility("hidden"))) int imgxf_lut_device_u8(const imgxf_view* src, const imgxf_view* dst,
+                                                                         const uint8_t* lut_dev, void* stream) {
+    const View s = make_view(src), d = make_view(dst);
+    if (d.n > 65535) return IMGXF_ERR_SHAPE;
+    LutArg arg;
+    memset(&arg, 0, sizeof(arg));
+    hipLaunchKernelGGL(lut_apply_kernel, dim3(blocks_for((int64_t)d.h * d.rowbytes() / 16), (unsigned)d.n), dim3(256), 0,
+                       (hipStream_t)stream, s, d, (const u8*)lut_dev, arg);
+    return launch_status();
+}

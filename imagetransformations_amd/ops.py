@@ -484,6 +484,34 @@ def equalize(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def rgb2yuv(t: torch.Tensor) -> torch.Tensor:
+    """cv2.cvtColor(img, cv2.COLOR_RGB2YUV) for 8-bit RGB (parity unpinned: OpenCV's integer definition)."""
+    t = _check_u8(t)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_rgb2yuv_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), _stream())
+    return out
+
+
+def yuv2rgb(t: torch.Tensor) -> torch.Tensor:
+    """cv2.cvtColor(img, cv2.COLOR_YUV2RGB) for 8-bit YUV (parity unpinned)."""
+    t = _check_u8(t)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_yuv2rgb_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), _stream())
+    return out
+
+
+def equalize_hist_cv(t: torch.Tensor, channel: int = 0) -> torch.Tensor:
+    """cv2.equalizeHist applied to one channel of an interleaved image, per frame (parity unpinned)."""
+    t = _check_u8(t)
+    h, w, c = _hwc(t)
+    n = t.shape[0] if t.dim() == 4 else 1
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    ws = torch.empty(max(1, n * c * 256 * 5 // 4 + 1), dtype=torch.int32, device=t.device)
+    F.call("imgxf_equalize_hist_cv_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), int(channel), ws.data_ptr(),
+           ws.numel() * 4, _stream())
+    return out
+
+
 def channel_histogram(t: torch.Tensor) -> torch.Tensor:
     """[N, C, 256] int32 histogram of a [N,H,W,C] / [H,W,C] / [H,W] uint8 tensor."""
     t = _check_u8(t)

@@ -1,8 +1,9 @@
 """`TransformationPool` members that sit on the hot path, with the
 reference's static-method style and argument meaning
-(/root/reference/pipenline/cifar_image_transformations.py:37-129).  The remaining member
-(histogram_equalization: cv2 RGB<->YUV + equalizeHist, parity unpinnable here) is a SURVEY §8f "next" row and is not provided yet:
-asking for them raises AttributeError rather than silently running on the CPU."""
+(/root/reference/pipenline/cifar_image_transformations.py:37-129): all ten are provided.  The two
+OpenCV-backed ones (`motion_blur`, `histogram_equalization`) are parity-unpinned (cv2 is not
+installed where this was built; they follow OpenCV's definitions), the other eight are bit-exact
+against Pillow / the reference's NumPy expressions."""
 from __future__ import annotations
 
 import random
@@ -17,6 +18,13 @@ from .transformation import _device, _download, _upload
 
 
 class TransformationPool:
+    def histogram_equalization(image):
+        """cifar_image_transformations.py:122-129: RGB -> YUV, cv2.equalizeHist on Y, YUV -> RGB.
+        Parity unpinned (OpenCV is not installed where this was built): the kernels follow
+        OpenCV's 8-bit integer definitions of the three calls."""
+        t = _upload(image)
+        return _download(ops.yuv2rgb(ops.equalize_hist_cv(ops.rgb2yuv(t), 0)))
+
     def gaussian_noise(image, severity=None):
         """cifar_image_transformations.py:39-48.  Noise drawn on the host from np.random (same
         stream as the reference for the same seed), added and clipped on the device in float64."""

@@ -184,6 +184,16 @@ int imgxf_equalize_u8(const imgxf_view* src, const imgxf_view* dst, void* worksp
                       void* stream);
 int imgxf_channel_histogram_u8(const imgxf_view* src, uint32_t* hist, void* stream);
 
+/* ---- TransformationPool.histogram_equalization  cifar_image_transformations.py:122-129 -------
+ * cv2.cvtColor(RGB2YUV / YUV2RGB) for 8-bit images (integer BT.601, yuv_shift 14) and
+ * cv2.equalizeHist applied to one channel of an interleaved view.  PARITY UNPINNED: OpenCV is not
+ * installed in the build container; the arithmetic follows OpenCV's integer definitions.
+ * workspace of equalize_hist_cv: >= n*c*256*5 bytes, 4-byte aligned. */
+int imgxf_rgb2yuv_u8(const imgxf_view* src, const imgxf_view* dst, void* stream);
+int imgxf_yuv2rgb_u8(const imgxf_view* src, const imgxf_view* dst, void* stream);
+int imgxf_equalize_hist_cv_u8(const imgxf_view* src, const imgxf_view* dst, int channel, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---- ImageFilter.BoxBlur / ImageFilter.GaussianBlur — libImaging BoxBlur.c --------------------
  * (TransformationPool.defocus_blur, cifar_image_transformations.py:72-77.)  `passes` box passes
  * along x then along y, each in exact uint32 arithmetic with replicated edges and a uint8

@@ -883,6 +883,56 @@ def apply_background_change(img, bg_color):
 # scipy.stats.entropy in tests/test_oracle_vs_libs.py.
 # ----------------------------------------------------------------------------
 
+# ---- TransformationPool.histogram_equalization (cifar_image_transformations.py:122-129) -------
+# PARITY UNPINNED: cv2 is not installed; OpenCV's 8-bit integer definitions restated
+# (imgproc color_yuv.simd.hpp RGB2YCrCb_i<uchar> / YCrCb2RGB_i<uchar> with the YUV coefficient
+# sets, yuv_shift = 14; histogram.cpp equalizeHist).
+
+def _descale14(x):
+    return (x + (1 << 13)) >> 14          # CV_DESCALE, arithmetic shift
+
+
+def rgb2yuv_cv(img):
+    a = np.asarray(img, np.uint8).astype(np.int64)
+    R, G, B = a[..., 0], a[..., 1], a[..., 2]
+    Y = _descale14(R * 4899 + G * 9617 + B * 1868)
+    V = _descale14((R - Y) * 14369 + (128 << 14))
+    U = _descale14((B - Y) * 8061 + (128 << 14))
+    return np.clip(np.stack([Y, U, V], axis=-1), 0, 255).astype(np.uint8)
+
+
+def yuv2rgb_cv(img):
+    a = np.asarray(img, np.uint8).astype(np.int64)
+    Y, U, V = a[..., 0], a[..., 1] - 128, a[..., 2] - 128
+    b = Y + _descale14(U * 33292)
+    g = Y + _descale14(U * -6472 + V * -9519)
+    r = Y + _descale14(V * 18678)
+    return np.clip(np.stack([r, g, b], axis=-1), 0, 255).astype(np.uint8)
+
+
+def equalize_hist_cv(gray):
+    """cv2.equalizeHist of one 8-bit plane."""
+    g = np.asarray(gray, np.uint8)
+    hist = np.bincount(g.ravel(), minlength=256)
+    total = int(g.size)
+    i = int(np.nonzero(hist)[0][0])
+    if hist[i] == total:
+        return np.full_like(g, i)
+    scale = np.float32(255.0) / np.float32(total - int(hist[i]))
+    lut = np.zeros(256, np.uint8)
+    acc = 0
+    for k in range(i + 1, 256):
+        acc += int(hist[k])
+        lut[k] = np.clip(np.rint(np.float32(acc) * scale), 0, 255)     # saturate_cast<uchar>(float): round half even
+    return lut[g]
+
+
+def histogram_equalization(img):
+    yuv = rgb2yuv_cv(img)
+    yuv[..., 0] = equalize_hist_cv(yuv[..., 0])
+    return yuv2rgb_cv(yuv)
+
+
 def vert_flip(img):
     """fall_2025/transformations_code:39-41: img.transpose(FLIP_LEFT_RIGHT)."""
     return np.ascontiguousarray(np.asarray(img)[:, ::-1])

@@ -177,7 +177,7 @@ def test_transformation_pool_members(device):
         assert np.array_equal(np.asarray(TransformationPool.enhance_brightness(img, f)),
                               np.asarray(ImageEnhance.Brightness(img).enhance(f)))
     with pytest.raises(AttributeError):
-        TransformationPool.histogram_equalization(img)    # "next" tier: absent, not a CPU fallback
+        TransformationPool.not_a_member(img)              # unknown members are absent, never a CPU fallback
 
 
 @pytest.mark.parametrize("hw", [(32, 32), (37, 61), (334, 500), (270, 480)])
@@ -405,3 +405,31 @@ def test_batched_driver_equals_per_image_driver(device):
         for j, (a, b) in enumerate(zip(got, want)):
             if b is imgs[j // 8][0]:
                 assert a is b
+
+
+def test_histogram_equalization_matches_oracle(device):
+    """TransformationPool.histogram_equalization (cv2 RGB2YUV -> equalizeHist(Y) -> YUV2RGB):
+    HIP kernels == the oracle's restatement of OpenCV's integer definitions, bit for bit
+    (parity with a real cv2 build is unpinned: OpenCV is not installed here)."""
+    from imagetransformations_amd import ops
+    from imagetransformations_amd.pool import TransformationPool
+    for hw in ((32, 32), (37, 61), (48, 64)):
+        a = synth(90, *hw)
+        flat = np.full((hw[0], hw[1], 3), 93, np.uint8)
+        dark = (synth(91, *hw) // 8).astype(np.uint8)
+        for img in (a, flat, dark):
+            t = torch.from_numpy(img).to(device)
+            yuv = ops.rgb2yuv(t).cpu().numpy()
+            assert np.array_equal(yuv, O.rgb2yuv_cv(img))
+            assert np.array_equal(ops.yuv2rgb(t).cpu().numpy(), O.yuv2rgb_cv(img))
+            eq = ops.equalize_hist_cv(torch.from_numpy(yuv).to(device), 0).cpu().numpy()
+            want = yuv.copy(); want[..., 0] = O.equalize_hist_cv(yuv[..., 0])
+            assert np.array_equal(eq, want)
+            got = np.asarray(TransformationPool.histogram_equalization(Image.fromarray(img)))
+            assert np.array_equal(got, O.histogram_equalization(img))
+    # batch: per-frame tables
+    batch = np.stack([synth(92, 40, 48), (synth(93, 40, 48) // 3).astype(np.uint8)])
+    out = ops.equalize_hist_cv(torch.from_numpy(batch).to(device), 0).cpu().numpy()
+    for i in range(2):
+        want = batch[i].copy(); want[..., 0] = O.equalize_hist_cv(batch[i][..., 0])
+        assert np.array_equal(out[i], want)

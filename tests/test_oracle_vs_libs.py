@@ -172,3 +172,27 @@ def test_resize_filters_and_flip_vs_pillow():
         if cs >= 1 and h >= cs:
             x, y = int(rng.integers(0, w - cs + 1)), int(rng.integers(0, h - cs + 1))
             assert np.array_equal(np.asarray(img.crop((x, y, x + cs, y + cs)).resize((32, 32))), O.rand_crop(a, x, y))
+
+
+def test_cv_colour_space_restatement_properties():
+    """cv2 is not installed, so the RGB<->YUV / equalizeHist restatement cannot be pinned; what can
+    be checked without it: the forward coefficients are BT.601 at 14 fractional bits, greys map
+    to U = V = 128 and back exactly, a round trip stays within the +-2 of two 8-bit quantisations,
+    and equalizeHist is monotone, keeps the darkest level at 0 and reaches 255."""
+    assert (round(0.299 * 16384), round(0.587 * 16384), round(0.114 * 16384)) == (4899, 9617, 1868)
+    assert (round(0.492 * 16384), round(0.877 * 16384)) == (8061, 14369)
+    assert (round(2.032 * 16384), round(-0.395 * 16384), round(-0.581 * 16384), round(1.140 * 16384)) == (33292, -6472, -9519, 18678)
+    g = np.repeat(np.arange(256, dtype=np.uint8)[:, None, None], 3, axis=2)
+    yuv = O.rgb2yuv_cv(g)
+    assert np.array_equal(yuv[..., 0], g[..., 0]) and (yuv[..., 1:] == 128).all()
+    assert np.array_equal(O.yuv2rgb_cv(yuv), g)
+    a = synth(95, 64, 64)
+    back = O.yuv2rgb_cv(O.rgb2yuv_cv(a)).astype(int)
+    inside = (O.rgb2yuv_cv(a)[..., 1:] > 0).all(-1) & (O.rgb2yuv_cv(a)[..., 1:] < 255).all(-1)
+    assert np.abs(back - a)[inside].max() <= 2
+    y = (synth(96, 50, 50)[..., 0] // 3 + 20).astype(np.uint8)
+    e = O.equalize_hist_cv(y)
+    order = np.argsort(y.ravel(), kind="stable")
+    assert (np.diff(e.ravel()[order].astype(int)) >= 0).all()
+    assert e[y == y.min()].max() == 0 and e.max() == 255
+    assert np.array_equal(O.equalize_hist_cv(np.full((5, 5), 9, np.uint8)), np.full((5, 5), 9, np.uint8))
