@@ -36,6 +36,7 @@ for f in os.listdir(D):
             groups[stem[:i]][t] = (stem[i + len(t) + 2:], f); break
 
 stats = collections.defaultdict(list)
+fixed_vs_float = []          # (radius, psnr float definition, psnr OpenCV fixed-point restatement, max |diff|, fraction differing)
 mism = collections.Counter()
 for name, ts in sorted(groups.items()):
     ids = [t for t, (v, _) in ts.items() if IDENT.get(t) == v]
@@ -51,8 +52,19 @@ for name, ts in sorted(groups.items()):
         if out.shape != ref.shape:
             mism[t] += 1; continue
         stats[t].append(psnr(jpeg(out), ref))
+        if t == "blur" and float(v) > 0:
+            fx = O.gaussian_blur_cv_fixed(proxy, O.blur_ksize(float(v)), float(v))
+            fixed_vs_float.append((float(v), stats[t][-1], psnr(jpeg(fx), ref),
+                                   int(np.abs(fx.astype(int) - out).max()), float((fx != out).mean())))
 with open(os.path.join(HERE, "reference_outputs_summary.tsv"), "w") as fh:
     fh.write("transformation\tcases\tsize_mismatches\tmin_psnr_db\tmedian_psnr_db\n")
     for t in sorted(stats):
         v = np.array(stats[t]); line = f"{t}\t{len(v)}\t{mism[t]}\t{v.min():.1f}\t{np.median(v):.1f}"
         print(line); fh.write(line + "\n")
+a = np.array(fixed_vs_float)
+with open(os.path.join(HERE, "reference_outputs_blur_fixed_vs_float.tsv"), "w") as fh:
+    fh.write("radius\tpsnr_float_definition_db\tpsnr_cv_fixed_point_db\tmax_abs_diff\tfraction_differing\n")
+    for row in sorted(fixed_vs_float):
+        fh.write("%.1f\t%.2f\t%.2f\t%d\t%.4f\n" % row)
+print("blur: float definition %.2f dB, OpenCV fixed-point restatement %.2f dB on average; fixed-point better in %d of %d"
+      % (a[:, 1].mean(), a[:, 2].mean(), int((a[:, 2] > a[:, 1]).sum()), len(a)))
