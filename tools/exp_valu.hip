@@ -31,6 +31,18 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
             if (KIND == 13) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(dd[i]) : "v"(dd[(i + 1) % CHAINS]));
             if (KIND == 14) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(u[i]), "v"(u[(i + 1) % CHAINS]) : "vcc");
             if (KIND == 15) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 16) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
+            if (KIND == 17) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
+            if (KIND == 18) asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
+            if (KIND == 19) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
+            if (KIND == 20) asm volatile("v_pk_mov_b32 %0, %0, %1 op_sel:[1,0]" : "+v"(dd[i]) : "v"(dd[(i + 1) % CHAINS]));
+            if (KIND == 21) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 22) asm volatile("v_pk_mad_u16 %0, %1, %2, %0" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
+            if (KIND == 23) asm volatile("v_sqrt_f32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) % CHAINS]));
+            if (KIND == 24) asm volatile("v_floor_f32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) % CHAINS]));
+            if (KIND == 25) asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 26) asm volatile("v_mul_i32_i24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
+            if (KIND == 27) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
         }
     }
     float s = 0;
@@ -56,5 +68,8 @@ int main() {
     run<8>("v_alignbit_b32"); run<7>("v_cvt_pk_u8_f32"); run<15>("v_mov_b32_dpp wave_shr");
     run<6>("v_pk_fma_f32"); run<3>("v_add_f64"); run<13>("v_mul_f64"); run<4>("v_fma_f64"); run<9>("v_floor_f64"); run<10>("v_cvt_i32_f64");
     run<5>("v_lshl_add_u64"); run<11>("v_mad_u64_u32");
+    run<16>("v_mad_u32_u24"); run<17>("v_perm_b32"); run<18>("v_dot2_u32_u16"); run<19>("v_dot4_u32_u8"); run<20>("v_pk_mov_b32");
+    run<21>("v_mul_lo_u32"); run<22>("v_pk_mad_u16"); run<23>("v_sqrt_f32"); run<24>("v_floor_f32"); run<25>("v_bfe_u32");
+    run<26>("v_mul_i32_i24_sdwa"); run<27>("v_add3_u32");
     return 0;
 }
