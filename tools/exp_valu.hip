@@ -10,6 +10,7 @@
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float* out, float seed) {
     float a[CHAINS]; uint32_t u[CHAINS]; double dd[CHAINS]; uint64_t q[CHAINS];
+    const uint64_t mask = __builtin_amdgcn_read_exec() ^ 0x5555555555555555ull;
 #pragma unroll
     for (int i = 0; i < CHAINS; ++i) { a[i] = seed + i + threadIdx.x; u[i] = (uint32_t)(threadIdx.x * 2654435761u + i); dd[i] = a[i]; q[i] = u[i]; }
     for (int it = 0; it < N_ITER; ++it) {
@@ -42,6 +43,18 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
             if (KIND == 24) asm volatile("v_floor_f32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) % CHAINS]));
             if (KIND == 25) asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
             if (KIND == 26) asm volatile("v_mul_i32_i24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
+            if (KIND == 28) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "s"(mask));
+            if (KIND == 29) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 30) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) % CHAINS]));
+            if (KIND == 31) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) % CHAINS]));
+            if (KIND == 32) asm volatile("v_and_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 33) asm volatile("v_lshrrev_b32 %0, 8, %1" : "=v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 34) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) % CHAINS]));
+            if (KIND == 35) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 36) asm volatile("v_or_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 37) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) % CHAINS]), "v"(seed));
+            if (KIND == 38) asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]) : "vcc");
+            if (KIND == 39) asm volatile("v_cmp_lt_u32 s[20:21], %1, %2\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]) : "s20", "s21");
             if (KIND == 27) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
         }
     }
@@ -71,5 +84,8 @@ int main() {
     run<16>("v_mad_u32_u24"); run<17>("v_perm_b32"); run<18>("v_dot2_u32_u16"); run<19>("v_dot4_u32_u8"); run<20>("v_pk_mov_b32");
     run<21>("v_mul_lo_u32"); run<22>("v_pk_mad_u16"); run<23>("v_sqrt_f32"); run<24>("v_floor_f32"); run<25>("v_bfe_u32");
     run<26>("v_mul_i32_i24_sdwa"); run<27>("v_add3_u32");
+    run<28>("v_cndmask_b32_e64 sgpr"); run<29>("v_cndmask_b32_e32 vcc"); run<30>("v_sub_f32"); run<31>("v_mul_f32"); run<32>("v_and_b32");
+    run<38>("cmp+cndmask via vcc (2 instr)"); run<39>("cmp+cndmask via sgpr pair (2 instr)");
+    run<33>("v_lshrrev_b32"); run<34>("v_max_f32"); run<35>("v_mov_b32"); run<36>("v_or_b32"); run<37>("v_fmac_f32");
     return 0;
 }
