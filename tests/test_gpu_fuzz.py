@@ -1,0 +1,98 @@
+"""Seeded random geometries through the fast paths added late in round 1 (marching dilation,
+RGB composite, LDS-staged Lanczos, fp32 shear with fp64 hand-back, LDS-DMA nearest rotation,
+marching Gaussian with static slots, strided batch views) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import imgxf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def rnd_image(rng, h, w, c=3):
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        return rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+    if kind == 1:                                    # smooth ramps + noise: many near-integer interpolants
+        y, x = np.mgrid[0:h, 0:w]
+        base = (x * 255 // max(w - 1, 1) + y * 3) % 256
+        return np.stack([(base + k * 40 + rng.integers(0, 3, (h, w))) % 256 for k in range(c)], -1).astype(np.uint8)
+    a = np.zeros((h, w, c), np.uint8)                # flat regions with sparse spikes
+    a[rng.random((h, w)) < 0.02] = rng.integers(1, 256, c)
+    return a
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_aligned_fast_paths(device, seed):
+    from imagetransformations_amd import ops
+    rng = np.random.default_rng(1000 + seed)
+    h = int(rng.integers(40, 200))
+    w = int(rng.integers(8, 90)) * 16                # 16-pixel multiples: rows are 16-byte aligned for c = 1 and 3
+    a = rnd_image(rng, h, w)
+    t = dev(a, device)
+    # nearest rotation (LDS-DMA staging) and bilinear precise
+    ang = float(rng.uniform(-180, 180))
+    assert np.array_equal(host(ops.rotate(t, -ang, ops.NEAREST, (0, 0, 0))), O.apply_rotation(a, ang)), ("nearest", h, w, ang)
+    m = O.rotate_zoom_matrix(w, h, float(rng.uniform(-60, 60)), float(rng.uniform(0.7, 2.0)))
+    assert np.array_equal(host(ops.affine(t, m, (w, h), ops.BILINEAR, (1, 2, 3), precise=True)),
+                          O.affine_bilinear(a, (w, h), m, fill=(1, 2, 3))), ("bilinear", h, w, m)
+    # shear (fp32 cubic + fp64 hand-back)
+    sh = float(rng.choice([0.1, 0.2, 0.30000000000000004, 0.5, 0.8, 1.0]))
+    nw, ms = O.shear_geometry(w, h, sh)
+    assert np.array_equal(host(ops.affine(t, ms, (nw, h), ops.BICUBIC, (255, 255, 255), precise=True)), O.apply_shear(a, sh)), ("shear", h, w, sh)
+    # Lanczos / bicubic resize through the LDS-staged horizontal pass
+    sc = float(rng.uniform(0.6, 1.6))
+    size = (max(1, int(w * sc)), max(1, int(h * sc)))
+    for flt in (O.RESAMPLE_LANCZOS, O.RESAMPLE_BICUBIC):
+        assert np.array_equal(host(ops.resize(t, size, flt)), O.resize(a, size, flt)), ("resize", h, w, size, flt)
+    # Gaussian (marching kernels where the row is wider than 1 KiB, tiled otherwise)
+    r = float(rng.choice([0.5, 5 / 6, 1.0, 1.5, 2.0, 3.5]))
+    k = O.blur_ksize(r)
+    if h > k and w > k:
+        out, f32 = ops.gaussian_blur(t, k, r, return_f32=True)
+        ref = O.gaussian_blur_f64(a, k, r)
+        assert (np.abs(host(f32) - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0)).all(), ("gauss", h, w, k)
+    # mask stage
+    g = a[..., 0]
+    mask = g > np.percentile(g, 90)
+    mt = dev((mask * rng.integers(1, 256)).astype(np.uint8), device)
+    assert np.array_equal(host(ops.dilate_cross(mt, 3)), (O.binary_dilation_cross(mask, 3) * 255).astype(np.uint8)), ("dilate", h, w)
+    b = rnd_image(rng, h, w)
+    fg = (O.binary_dilation_cross(mask, 3) * 255).astype(np.uint8)
+    assert np.array_equal(host(ops.composite(t, dev(b, device), dev(fg, device))), O.composite(a, b, fg)), ("composite", h, w)
+    bg = host(ops.new(t, h, w, (7, 130, 251)))
+    assert (bg == np.array([7, 130, 251], np.uint8)).all()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_strided_batches(device, seed):
+    """Every other frame of a batch, and a column window of wider frames (row stride > row bytes)."""
+    from imagetransformations_amd import ops
+    rng = np.random.default_rng(2000 + seed)
+    h, w = int(rng.integers(30, 80)), int(rng.integers(5, 20)) * 16
+    big = np.stack([rnd_image(rng, h, w + 32) for _ in range(4)])
+    tb = dev(big, device)
+    win = tb[::2, :, 16:16 + w]                                   # frame stride x2, row stride w+32, 48-byte column offset
+    ref = [np.ascontiguousarray(big[i, :, 16:16 + w]) for i in (0, 2)]
+    ang = float(rng.uniform(-90, 90))
+    out = host(ops.rotate(win, -ang, ops.NEAREST, (0, 0, 0)))
+    lz = host(ops.resize_lanczos(win, (w + 9, h - 5)))
+    g = host(ops.gaussian_blur(win, 5, 5 / 6))
+    sm = host(ops.solarize(win, 99))
+    eq = host(ops.equalize(win))
+    for j in range(2):
+        assert np.array_equal(out[j], O.apply_rotation(ref[j], ang))
+        assert np.array_equal(lz[j], O.resize_lanczos(ref[j], (w + 9, h - 5)))
+        d = np.abs(g[j].astype(int) - O.gaussian_blur(ref[j], 5, 5 / 6).astype(int))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3
+        assert np.array_equal(sm[j], O.solarize(ref[j], 99))
+        assert np.array_equal(eq[j], O.equalize(ref[j]))
