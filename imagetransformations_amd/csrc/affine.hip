@@ -8,6 +8,7 @@
 // rotated strip that stays in the XCD's L2 while neighbouring patches reuse it.
 #include "imgxf_common.h"
 #include <math.h>
+#include <algorithm>
 #include <string.h>
 #include <stdlib.h>
 
@@ -475,25 +476,23 @@ __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __buil
 // from LDS with one ds_read2_b32 per source row.  Coordinates, guard logic and the exact
 // fp64 hand-back are the same as in affine_bilinear_kernel.
 // ---------------------------------------------------------------------------------------
-template <bool PRECISE, int PITCH, bool DBG>
-__global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d, AffineParams P, View dbg,
-                                                                  int ntx, int nty) {
-    constexpr int C = 3, TXG = 8, WX = 1, TR = 8, BW = 32, BH = 32;   // square tile: smallest rotated bbox
+// One output tile of the LDS-staged bilinear kernels.  BH = 32: the square tile (smallest rotated
+// bounding box), interior fast path or general per-pixel path.  BH = 64 (INTERIOR): interior
+// tiles only, a lane computes 8 pixels in two pieces — halves the per-tile setup / staging
+// bookkeeping per pixel and stages 1.03 instead of 1.67 source pixels per output pixel at
+// 30 deg / 1.5x; returns false BEFORE touching LDS when the tile is not interior, and the caller
+// then runs its two 32x32 halves through the BH = 32 body.
+template <bool PRECISE, int PITCH, bool DBG, int BH, bool INTERIOR>
+__device__ __forceinline__ bool bilinear_tile(const View& s, const View& d, const AffineParams& P, const View& dbg,
+                                              u32* srct, u32 (*stage)[64 * 3 + 2 * (64 / 8) + 4],
+                                              int f, int txb, int tyb, int lane, int wave) {
+    constexpr int C = 3, TXG = 8, WX = 1, TR = 8, BW = 32, NH = BH / 32;
     constexpr float GUARD = 1.2e-4f;
     constexpr int FONE = 1 << 24, FHALF = 1 << 23, CG32 = 1 << 6;   // 8.24 tile-relative coordinates
-    extern __shared__ __attribute__((aligned(16))) u32 srct[];      // bbox pixels, RGBX, row pitch PITCH
-    __shared__ __attribute__((aligned(16))) u32 stage[4][64 * C + 2 * (64 / TXG) + 4];
-
-    // tiles of one frame are numbered x-fastest and remapped so each XCD walks a contiguous range
-    const int nblocks = ntx * nty;
-    const int orig = blockIdx.x, xcd = orig & 7, q = nblocks >> 3, r = nblocks & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int f = blockIdx.y;
-    // logical / ntx by the host's reciprocal (exact: logical * ntx < 2^32) keeps the tile setup scalar
-    const int tyb = P.ntx_magic ? (int)__umulhi((u32)logical, P.ntx_magic) : logical, txb = logical - tyb * ntx;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lx = ((wave % WX) * TXG + (lane % TXG)) * 4, ly = (wave / WX) * TR + lane / TXG;
-    const int x0 = txb * BW + lx, y = tyb * BH + ly;
+    const int lx = ((wave % WX) * TXG + (lane % TXG)) * 4;
+    int ly = (wave / WX) * TR * NH + lane / TXG;                  // MODE 1 revisits ly / y per half
+    const int x0 = txb * BW + lx;
+    int y = tyb * BH + ly;
     const int wx0 = txb * BW + (wave % WX) * TXG * 4, wy0 = tyb * BH + (wave / WX) * TR;
     const bool staged = wx0 + TXG * 4 <= d.w && wy0 + TR <= d.h &&
                         ((((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs | (uintptr_t)(wx0 * C)) & 15) == 0;
@@ -513,12 +512,16 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
     const int sx_lo = max(ux_lo, 0), sx_hi = min((int)(xhi >> 40) + 1, s.w - 1);
     const int sy_lo = max(uy_lo, 0), sy_hi = min((int)(yhi >> 40) + 1, s.h - 1);
     const int bwc = sx_hi - sx_lo + 1, bhc = sy_hi - sy_lo + 1;    // <= 0: tile sees no source pixel
+    // interior tile (block-uniform): inside the output, and the 2x2 support of every pixel inside the source
+    const bool clean = ux_lo >= 0 && uy_lo >= 0 && (int)(xhi >> 40) + 1 <= s.w - 1 && (int)(yhi >> 40) + 1 <= s.h - 1 &&
+                       txb * BW + BW <= d.w && tyb * BH + BH <= d.h;
+    if (INTERIOR && !clean) return false;
 
     // ---- stage the bounding box: wave w copies rows w, w+4, ...; lanes walk consecutive pixels
     // of a source row (unaligned 4-byte loads at a 3-byte lane stride: two cache lines per
     // instruction).  The frame's very last pixel cannot be read with a 4-byte load, so the one
     // tile that owns it reads that pixel from 1 byte earlier and shifts.
-    stage_bbox<PITCH, 9>(s, sp, srct, lane, wave, sx_lo, sy_lo, sx_hi, sy_hi, bwc, bhc);
+    stage_bbox<PITCH, BH == 64 ? 13 : 9>(s, sp, srct, lane, wave, sx_lo, sy_lo, sx_hi, sy_hi, bwc, bhc);
     __syncthreads();
 
     auto exact_pixel = [&](int x, u8 (&px)[C], float (&vv)[C]) {
@@ -562,10 +565,15 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
     // pixel 0's rounded 8.24 value plus the host-rounded step sx[k] (|error| <= 2^-24 px in total,
     // so |fp32 - fp64| <= 2*255*6e-8 + 3*7.6e-6 = 5.3e-5 < GUARD).  Pixels that need libImaging's
     // fp64 sequence are collected in a lane mask and handled after the loop.
-    const bool clean = ux_lo >= 0 && uy_lo >= 0 && (int)(xhi >> 40) + 1 <= s.w - 1 && (int)(yhi >> 40) + 1 <= s.h - 1 &&
-                       txb * BW + BW <= d.w && tyb * BH + BH <= d.h;
     if (clean) {
-        const int Xb = (int)((XL + 32768) >> 16), Yb = (int)((YL + 32768) >> 16);   // rounded: |error| <= 2^-25
+      const bool dst16 = ((((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs | (uintptr_t)(wx0 * C)) & 15) == 0;
+#pragma unroll
+      for (int half = 0; half < NH; ++half) {
+        if (NH > 1) { ly = (wave * NH + half) * TR + lane / TXG; y = tyb * BH + ly; }
+        const int64_t XLh = NH > 1 ? XT + lx * P.q0 + ly * P.q1 - ((int64_t)ux_lo << 40) : XL;
+        const int64_t YLh = NH > 1 ? YT + lx * P.q3 + ly * P.q4 - ((int64_t)uy_lo << 40) : YL;
+        const bool staged_h = NH > 1 ? dst16 : staged;
+        const int Xb = (int)((XLh + 32768) >> 16), Yb = (int)((YLh + 32768) >> 16);   // rounded: |error| <= 2^-25
         u32 od[C] = {0u, 0u, 0u};
         u32 need = 0;                                    // bit k: pixel k is handed to the slow path
         float vf[DBG ? 4 : 1][C];
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
                 for (int j = 0; j < C; ++j) fp[j] = vf[k][j];
             }
         }
-        if (staged) {
+        if (staged_h) {
             u8* seg = d.row(f, y) + (x0 - (lane % TXG) * 4) * C;
             staged_store<C, TXG>(stage[wave], od, lane, seg);
         } else {
@@ -672,8 +680,10 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
                 for (int e = 0; e < 4 * C; ++e) dp[e] = (u8)(od[e >> 2] >> ((e & 3) * 8));
             }
         }
-        return;
+      }   // half
+      return true;
     }
+    if (INTERIOR) return true;      // (unreachable: non-interior tiles left before staging)
     u8 out[4 * C];
     float vf[4][C];
 #pragma unroll
@@ -750,9 +760,9 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
     if (staged) {
         u8* seg = d.row(f, y) + (x0 - (lane % TXG) * 4) * C;
         staged_store<C, TXG>(stage[wave], od, lane, seg);
-        return;
+        return true;
     }
-    if (!valid) return;
+    if (!valid) return true;
     u8* dp = d.row(f, y) + x0 * C;
     const int npx = min(4, d.w - x0);
     if (npx == 4 && ((((uintptr_t)dp) & 3) == 0)) {
@@ -766,6 +776,57 @@ __global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d
             dp[e] = v;
         }
     }
+    return true;
+}
+
+template <bool PRECISE, int PITCH, bool DBG>
+__global__ __launch_bounds__(256) void affine_bilinear_lds_kernel(View s, View d, AffineParams P, View dbg,
+                                                                  int ntx, int nty) {
+    extern __shared__ __attribute__((aligned(16))) u32 srct[];      // bbox pixels, RGBX, row pitch PITCH
+    __shared__ __attribute__((aligned(16))) u32 stage[4][64 * 3 + 2 * (64 / 8) + 4];
+    // tiles of one frame are numbered x-fastest and remapped so each XCD walks a contiguous range
+    const int nblocks = ntx * nty;
+    const int orig = blockIdx.x, xcd = orig & 7, q = nblocks >> 3, r = nblocks & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int f = blockIdx.y;
+    // logical / ntx by the host's reciprocal (exact: logical * ntx < 2^32) keeps the tile setup scalar
+    const int tyb = P.ntx_magic ? (int)__umulhi((u32)logical, P.ntx_magic) : logical, txb = logical - tyb * ntx;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    bilinear_tile<PRECISE, PITCH, DBG, 32, false>(s, d, P, dbg, srct, stage, f, txb, tyb, lane, wave);
+}
+
+// Interior 32x64 tiles (8 pixels per lane); tiles that are not interior leave at once and are
+// done by affine_bilinear_lds_list_kernel from the host's list (nty counts 64-row bands).
+template <bool PRECISE, int PITCH, bool DBG>
+__global__ __launch_bounds__(256) void affine_bilinear_lds_interior_kernel(View s, View d, AffineParams P, View dbg,
+                                                                           int ntx, int nty) {
+    extern __shared__ __attribute__((aligned(16))) u32 srct[];
+    __shared__ __attribute__((aligned(16))) u32 stage[4][64 * 3 + 2 * (64 / 8) + 4];
+    const int nblocks = ntx * nty;
+    const int orig = blockIdx.x, xcd = orig & 7, q = nblocks >> 3, r = nblocks & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int f = blockIdx.y;
+    const int tyb = P.ntx_magic ? (int)__umulhi((u32)logical, P.ntx_magic) : logical, txb = logical - tyb * ntx;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    bilinear_tile<PRECISE, PITCH, DBG, 64, true>(s, d, P, dbg, srct, stage, f, txb, tyb, lane, wave);
+}
+
+// The 32x64 tiles the interior pass skipped, as 32x32 tiles: workgroup 2e + c is half c of list entry e
+constexpr int BILINEAR_LIST_MAX = 896;
+struct TileList { int n; u32 idx[BILINEAR_LIST_MAX]; };
+
+template <bool PRECISE, int PITCH, bool DBG>
+__global__ __launch_bounds__(256) void affine_bilinear_lds_list_kernel(View s, View d, AffineParams P, View dbg,
+                                                                       int ntx, TileList list) {
+    extern __shared__ __attribute__((aligned(16))) u32 srct[];
+    __shared__ __attribute__((aligned(16))) u32 stage[4][64 * 3 + 2 * (64 / 8) + 4];
+    const int parent = (int)list.idx[blockIdx.x >> 1];
+    const int f = blockIdx.y;
+    const int ty64 = P.ntx_magic ? (int)__umulhi((u32)parent, P.ntx_magic) : parent, txb = parent - ty64 * ntx;
+    const int tyb = 2 * ty64 + (int)(blockIdx.x & 1);
+    if (tyb * 32 >= d.h) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    bilinear_tile<PRECISE, PITCH, DBG, 32, false>(s, d, P, dbg, srct, stage, f, txb, tyb, lane, wave);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1168,22 +1229,72 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
             if (bw <= 97 && bh <= 100 && (int64_t)ntx * nty < 0x7fffffff && d.n <= 65535) {
                 dim3 grid((unsigned)(ntx * nty), (unsigned)d.n);
                 P.ntx_magic = (u32)((((uint64_t)1 << 32) + ntx - 1) / ntx);   // ntx, nty <= 1024: exact; 0 when ntx == 1
+#define IMGXF_LDS_LAUNCH(KERNEL, PITCH, GRID, NTY, LDSB)                                            \
+    do {                                                                                           \
+        if (dbg.p) {                                                                               \
+            if (pr) hipLaunchKernelGGL((KERNEL<true, PITCH, true>), GRID, dim3(256), LDSB, st, s, d, P, dbg, ntx, NTY); \
+            else hipLaunchKernelGGL((KERNEL<false, PITCH, true>), GRID, dim3(256), LDSB, st, s, d, P, dbg, ntx, NTY); \
+        } else {                                                                                   \
+            if (pr) hipLaunchKernelGGL((KERNEL<true, PITCH, false>), GRID, dim3(256), LDSB, st, s, d, P, dbg, ntx, NTY); \
+            else hipLaunchKernelGGL((KERNEL<false, PITCH, false>), GRID, dim3(256), LDSB, st, s, d, P, dbg, ntx, NTY); \
+        }                                                                                          \
+    } while (0)
 #define IMGXF_LDS(PITCH)                                                                           \
     do {                                                                                           \
         const size_t lds = (size_t)PITCH * bh * 4 + 16;                                            \
-        if (dbg.p) {                                                                               \
-            if (pr) hipLaunchKernelGGL((affine_bilinear_lds_kernel<true, PITCH, true>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty); \
-            else hipLaunchKernelGGL((affine_bilinear_lds_kernel<false, PITCH, true>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty); \
-        } else {                                                                                   \
-            if (pr) hipLaunchKernelGGL((affine_bilinear_lds_kernel<true, PITCH, false>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty); \
-            else hipLaunchKernelGGL((affine_bilinear_lds_kernel<false, PITCH, false>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, nty); \
-        }                                                                                          \
+        IMGXF_LDS_LAUNCH(affine_bilinear_lds_kernel, PITCH, grid, nty, lds);                       \
         return launch_status();                                                                    \
     } while (0)
+                // 32x64 interior tiles + a host-built list of the others, when the taller tile's source
+                // box still fits the narrow LDS pitch and the list fits the launch arguments
+                const int bw64 = (int)ceil(fabs(m[0]) * 31 + fabs(m[1]) * 63) + 4;
+                const int bh64 = (int)ceil(fabs(m[3]) * 31 + fabs(m[4]) * 63) + 4;
+                static const bool no_tall = getenv("IMGXF_AFFINE_NO_TALL") != nullptr;
+                const int nty64 = (d.h + 63) / 64;
+                if (bw64 <= 49 && bh64 <= 64 && bw <= 49 && !no_tall && (int64_t)ntx * nty64 * ntx < ((int64_t)1 << 32)) {
+                    TileList list;
+                    list.n = 0;
+                    // the kernel's interior test (bilinear_tile<.., 64, true>), same integers
+                    const int64_t ax = 31 * P.q0, bx = 63 * P.q1, ay = 31 * P.q3, by = 63 * P.q4;
+                    const int64_t xlo_o = std::min(ax, (int64_t)0) + std::min(bx, (int64_t)0), xhi_o = std::max(ax, (int64_t)0) + std::max(bx, (int64_t)0);
+                    const int64_t ylo_o = std::min(ay, (int64_t)0) + std::min(by, (int64_t)0), yhi_o = std::max(ay, (int64_t)0) + std::max(by, (int64_t)0);
+                    for (int ty = 0; ty < nty64 && list.n <= BILINEAR_LIST_MAX; ++ty)
+                        for (int tx = 0; tx < ntx; ++tx) {
+                            const int64_t XT = P.x00 + (int64_t)(tx * 32) * P.q0 + (int64_t)(ty * 64) * P.q1;
+                            const int64_t YT = P.y00 + (int64_t)(tx * 32) * P.q3 + (int64_t)(ty * 64) * P.q4;
+                            const bool clean = (int)((XT + xlo_o) >> 40) >= 0 && (int)((YT + ylo_o) >> 40) >= 0 &&
+                                               (int)((XT + xhi_o) >> 40) + 1 <= s.w - 1 && (int)((YT + yhi_o) >> 40) + 1 <= s.h - 1 &&
+                                               tx * 32 + 32 <= d.w && ty * 64 + 64 <= d.h;
+                            if (!clean) {
+                                if (list.n < BILINEAR_LIST_MAX) list.idx[list.n] = (u32)(ty * ntx + tx);
+                                ++list.n;
+                            }
+                        }
+                    if (list.n <= BILINEAR_LIST_MAX) {
+                        if (list.n < ntx * nty64) {           // at least one interior tile
+                            dim3 grid64((unsigned)(ntx * nty64), (unsigned)d.n);
+                            IMGXF_LDS_LAUNCH(affine_bilinear_lds_interior_kernel, 49, grid64, nty64, (size_t)49 * bh64 * 4 + 16);
+                            IMGXF_CHECK(launch_status());
+                        }
+                        if (list.n > 0) {
+                            dim3 gridl((unsigned)(2 * list.n), (unsigned)d.n);
+                            const size_t lds = (size_t)49 * bh * 4 + 16;
+                            if (dbg.p) {
+                                if (pr) hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<true, 49, true>), gridl, dim3(256), lds, st, s, d, P, dbg, ntx, list);
+                                else hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<false, 49, true>), gridl, dim3(256), lds, st, s, d, P, dbg, ntx, list);
+                            } else {
+                                if (pr) hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<true, 49, false>), gridl, dim3(256), lds, st, s, d, P, dbg, ntx, list);
+                                else hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<false, 49, false>), gridl, dim3(256), lds, st, s, d, P, dbg, ntx, list);
+                            }
+                        }
+                        return launch_status();
+                    }
+                }
                 if (bw <= 49) IMGXF_LDS(49);
                 if (bw <= 65) IMGXF_LDS(65);
                 IMGXF_LDS(97);
 #undef IMGXF_LDS
+#undef IMGXF_LDS_LAUNCH
             }
         }
 #define IMGXF_BIL(CC, PR, TXG, WX)                                                                 \
