@@ -913,10 +913,13 @@ __global__ __launch_bounds__(256) void affine_nearest_lds_kernel(View s, View d,
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),    \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-constexpr int DCH = 11, DPITCH = DCH * 16;      // chunks and bytes per staged row
-
+// BH = 32 with DCHT = 11 chunks per staged row (box <= 49 pixels wide), or BH = 64 with DCHT = 13
+// (box <= 64 wide): the taller tile halves the per-tile setup per pixel, a lane then gathers
+// two groups of 4 pixels.
+template <int BH, int DCHT>
 __global__ __launch_bounds__(256) void affine_nearest_dma_kernel(View s, View d, AffineParams P, int ntx, int nty) {
-    constexpr int C = 3, TXG = 8, WX = 1, TR = 8, BW = 32, BH = 32;
+    constexpr int C = 3, TXG = 8, TR = 8, BW = 32, NH = BH / 32, DPITCH = DCHT * 16;
+    constexpr u32 DIVM = (65536u + DCHT - 1) / DCHT;                  // idx / DCHT == (idx * DIVM) >> 16 for idx < 2^12
     extern __shared__ __attribute__((aligned(16))) char srcb[];      // bhc x DPITCH bytes (+16)
     __shared__ __attribute__((aligned(16))) u32 stage[4][64 * C + 2 * (64 / TXG) + 4];
     const int nblocks = ntx * nty;
@@ -925,12 +928,9 @@ __global__ __launch_bounds__(256) void affine_nearest_dma_kernel(View s, View d,
     const int f = blockIdx.y;
     const int tyb = P.ntx_magic ? (int)__umulhi((u32)logical, P.ntx_magic) : logical, txb = logical - tyb * ntx;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lx = ((wave % WX) * TXG + (lane % TXG)) * 4, ly = (wave / WX) * TR + lane / TXG;
-    const int x0 = txb * BW + lx, y = tyb * BH + ly;
-    const int wx0 = txb * BW + (wave % WX) * TXG * 4, wy0 = tyb * BH + (wave / WX) * TR;
-    const bool staged = wx0 + TXG * 4 <= d.w && wy0 + TR <= d.h &&
-                        ((((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs | (uintptr_t)(wx0 * C)) & 15) == 0;
-    const bool valid = y < d.h && x0 < d.w;
+    const int lx = (lane % TXG) * 4;
+    const int x0 = txb * BW + lx;
+    const int wx0 = txb * BW;
     const u8* sp = s.p + (int64_t)f * s.fs;
 
     const int XT = P.fx[2] + P.fx[1] * (tyb * BH) + P.fx[0] * (txb * BW);
@@ -943,14 +943,12 @@ __global__ __launch_bounds__(256) void affine_nearest_dma_kernel(View s, View d,
     const int last_chunk = s.w * 3 - 16;               // chunks past the row end re-read its last one
 
     if (bwc > 0 && bhc > 0) {
-        const int nchunks = bhc * DCH;                 // <= 52 * 11
-        const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)srcb;
-        (void)lds0;
+        const int nchunks = bhc * DCHT;                // host: bhc * DCHT < 4096
         for (int base = wave * 64; base < nchunks; base += 256) {          // wave-uniform trip count
             const int idx = base + lane;
             if (idx < nchunks) {
-                const int row = (int)(((u32)idx * 5958u) >> 16);            // idx / 11 for idx < 2^13
-                const int ch = idx - row * DCH;
+                const int row = (int)(((u32)idx * DIVM) >> 16);
+                const int ch = idx - row * DCHT;
                 const u8* gp = sp + (int64_t)(sy_lo + row) * s.rs + min(a0 + ch * 16, last_chunk);
                 IMGXF_AFF_GLDS16(gp, srcb + base * 16);
             }
@@ -960,35 +958,43 @@ __global__ __launch_bounds__(256) void affine_nearest_dma_kernel(View s, View d,
     __syncthreads();
 
     const u32 fillw = (u32)P.fill[0] | ((u32)P.fill[1] << 8) | ((u32)P.fill[2] << 16);
-    const int XL = XT + lx * P.fx[0] + ly * P.fx[1], YL = YT + lx * P.fx[3] + ly * P.fx[4];
-    u32 px[4];
+    const bool dst16 = ((((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs | (uintptr_t)(wx0 * C)) & 15) == 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int xi = ((XL + k * P.fx[0]) >> 16) - sx_lo, yi = ((YL + k * P.fx[3]) >> 16) - sy_lo;
-        const bool in = bwc > 0 && bhc > 0 && (u32)xi < (u32)bwc && (u32)yi < (u32)bhc;
-        const int bo = in ? (int)__umul24((u32)yi, (u32)DPITCH) + (xi + sx_lo) * 3 - a0 : 0;
-        const u32* wp = (const u32*)(srcb + (bo & ~3));
-        const u32 lo = wp[0], hi = wp[1];
-        const u32 t = __builtin_amdgcn_alignbyte(hi, lo, (u32)bo & 3u);
-        px[k] = in ? (t & 0xffffffu) : fillw;
-    }
-    u32 od[3];
-    od[0] = px[0] | (px[1] << 24);
-    od[1] = (px[1] >> 8) | (px[2] << 16);
-    od[2] = (px[2] >> 16) | (px[3] << 8);
-    if (staged) {
-        u8* seg = d.row(f, y) + (x0 - (lane % TXG) * 4) * C;
-        staged_store<C, TXG>(stage[wave], od, lane, seg);
-        return;
-    }
-    if (!valid) return;
-    u8* dp = d.row(f, y) + x0 * C;
-    const int npx = min(4, d.w - x0);
-    if (npx == 4 && ((((uintptr_t)dp) & 3) == 0)) {
+    for (int half = 0; half < NH; ++half) {
+        const int ly = (wave * NH + half) * TR + lane / TXG;
+        const int y = tyb * BH + ly;
+        const int wy0 = tyb * BH + (wave * NH + half) * TR;
+        const bool staged = dst16 && wx0 + TXG * 4 <= d.w && wy0 + TR <= d.h;
+        const bool valid = y < d.h && x0 < d.w;
+        const int XL = XT + lx * P.fx[0] + ly * P.fx[1], YL = YT + lx * P.fx[3] + ly * P.fx[4];
+        u32 px[4];
 #pragma unroll
-        for (int qq = 0; qq < C; ++qq) ((u32*)dp)[qq] = od[qq];
-    } else {
-        for (int e = 0; e < npx * C; ++e) dp[e] = (u8)(px[e / 3] >> (8 * (e % 3)));
+        for (int k = 0; k < 4; ++k) {
+            const int xi = ((XL + k * P.fx[0]) >> 16) - sx_lo, yi = ((YL + k * P.fx[3]) >> 16) - sy_lo;
+            const bool in = bwc > 0 && bhc > 0 && (u32)xi < (u32)bwc && (u32)yi < (u32)bhc;
+            const int bo = in ? (int)__umul24((u32)yi, (u32)DPITCH) + (xi + sx_lo) * 3 - a0 : 0;
+            const u32* wp = (const u32*)(srcb + (bo & ~3));
+            const u32 lo = wp[0], hi = wp[1];
+            const u32 t = __builtin_amdgcn_alignbyte(hi, lo, (u32)bo & 3u);
+            px[k] = in ? (t & 0xffffffu) : fillw;
+        }
+        u32 od[3];
+        od[0] = px[0] | (px[1] << 24);
+        od[1] = (px[1] >> 8) | (px[2] << 16);
+        od[2] = (px[2] >> 16) | (px[3] << 8);
+        if (staged) {
+            u8* seg = d.row(f, y) + (x0 - (lane % TXG) * 4) * C;
+            staged_store<C, TXG>(stage[wave], od, lane, seg);
+        } else if (valid) {
+            u8* dp = d.row(f, y) + x0 * C;
+            const int npx = min(4, d.w - x0);
+            if (npx == 4 && ((((uintptr_t)dp) & 3) == 0)) {
+#pragma unroll
+                for (int qq = 0; qq < C; ++qq) ((u32*)dp)[qq] = od[qq];
+            } else {
+                for (int e = 0; e < npx * C; ++e) dp[e] = (u8)(px[e / 3] >> (8 * (e % 3)));
+            }
+        }
     }
 }
 
@@ -1186,7 +1192,17 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
             static const bool no_dma = getenv("IMGXF_AFFINE_NO_DMA") != nullptr;
             if (bw <= 49 && bh <= 52 && !no_dma && src->w * 3 >= 16 && (src->w * 3) % 16 == 0 &&
                 ((((uintptr_t)src->data) | (uintptr_t)src->row_stride | (uintptr_t)src->frame_stride) & 15) == 0) {
-                hipLaunchKernelGGL(affine_nearest_dma_kernel, grid, dim3(256), (size_t)DPITCH * bh + 32, st, s, d, P, ntx, nty);
+                // 32x64 tiles when their source box fits 13 chunks x 80 rows, else 32x32
+                const int bw64 = (int)ceil((fabs((double)P.fx[0]) * 31 + fabs((double)P.fx[1]) * 63) / 65536.0) + 3;
+                const int bh64 = (int)ceil((fabs((double)P.fx[3]) * 31 + fabs((double)P.fx[4]) * 63) / 65536.0) + 3;
+                static const bool no_tall = getenv("IMGXF_AFFINE_NO_TALL") != nullptr;
+                if (bw64 <= 64 && bh64 <= 80 && !no_tall) {
+                    const int nty64 = (d.h + 63) / 64;
+                    hipLaunchKernelGGL((affine_nearest_dma_kernel<64, 13>), dim3((unsigned)(ntx * nty64), (unsigned)d.n), dim3(256),
+                                       (size_t)13 * 16 * bh64 + 32, st, s, d, P, ntx, nty64);
+                } else {
+                    hipLaunchKernelGGL((affine_nearest_dma_kernel<32, 11>), grid, dim3(256), (size_t)11 * 16 * bh + 32, st, s, d, P, ntx, nty);
+                }
                 return launch_status();
             }
             if (bw <= 49) hipLaunchKernelGGL((affine_nearest_lds_kernel<49>), grid, dim3(256), (size_t)49 * bh * 4 + 16, st, s, d, P, ntx, nty);
