@@ -96,3 +96,33 @@ def test_fuzz_strided_batches(device, seed):
         assert d.max() <= 1 and (d != 0).mean() < 1e-3
         assert np.array_equal(sm[j], O.solarize(ref[j], 99))
         assert np.array_equal(eq[j], O.equalize(ref[j]))
+
+
+@pytest.mark.parametrize("hw", [(130, 256), (64, 64), (300, 480)])
+def test_bilinear_special_matrices(device, hw):
+    """Matrices that stress the interior / border-list split of the bilinear kernels: pure scale,
+    pure translation (partly and completely outside), anisotropic zoom-out, shear-like, a
+    different output size, and a flip (negative diagonal)."""
+    from imagetransformations_amd import ops
+    h, w = hw
+    rng = np.random.default_rng(h * 31 + w)
+    a = rnd_image(rng, h, w)
+    t = dev(a, device)
+    mats = [
+        ((0.5, 0, 0, 0, 0.5, 0), (w, h)),                       # 2x zoom-in of the top-left quarter
+        ((1, 0, 10.25, 0, 1, -7.5), (w, h)),                    # translation with fractions
+        ((1, 0, 5 * w, 0, 1, 0), (w, h)),                       # completely outside: all fill
+        ((1.7, 0, -20, 0, 2.3, -30), (w, h)),                   # anisotropic zoom-out with borders
+        ((1, 0.3, -15, 0.1, 1, 0), (w + 40, h)),                # shear-like, wider output
+        ((-1, 0, w, 0, 1, 0), (w, h)),                          # mirror
+        ((0.9, 0.05, 3.3, -0.04, 1.1, 2.2), (w // 2 + 3, h // 2 + 5)),   # small output
+    ]
+    for m, size in mats:
+        for fill in ((0, 0, 0), (9, 200, 77)):
+            want = O.affine_bilinear(a, size, m, fill=fill)
+            got = host(ops.affine(t, m, size, ops.BILINEAR, fill, precise=True))
+            assert np.array_equal(got, want), (hw, m, size, fill, int((got != want).sum()))
+        # batch of two frames through the same launch
+        batch = dev(np.stack([a, a[::-1].copy()]), device)
+        got2 = host(ops.affine(batch, m, size, ops.BILINEAR, (1, 2, 3), precise=True))
+        assert np.array_equal(got2[1], O.affine_bilinear(a[::-1].copy(), size, m, fill=(1, 2, 3))), (hw, m)
