@@ -26,6 +26,11 @@ struct imgxf_lanczos_plan {
     int* d_pk_x;             // [out_w][kpx]
     int* d_start_y;          // [out_h]
     int* d_pk_y;             // [out_h][kpy]
+    // 4-row groups for resample_v4_kernel: union window of KU4 input rows per group, coefficients of
+    // each of the group's rows re-indexed to it (0 = not usable)
+    int ku4;
+    int* d_start4_y;         // [ceil(out_h/4)]
+    int* d_pk4_y;            // [ceil(out_h/4)][4][ku4]
     uint8_t* d_tmp;          // [max_frames][in_h][out_w][c], only when both passes run
     int need_h, need_v;
 };
@@ -398,6 +403,52 @@ __global__ __launch_bounds__(256) void resample_v_fast_kernel(View s, View d, co
     *(uint4*)(d.row(f, yy) + (ck << 4)) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// ---- vertical pass, 4 output rows per lane.  The one-row kernel re-reads its KP input rows
+// for every output row (7x the output size through L2).  Four consecutive output rows share a
+// union window of KU input rows (KP + their window shifts); the host re-indexes each row's
+// coefficients to that window (zero outside its own), so the lane reads each input row of the
+// window once and feeds up to four accumulator sets: ~3 loads per output row instead of 7, no
+// dynamic register indexing.  Coefficients are wave-uniform (scalar loads), zero ones skipped.
+template <int KU>
+__global__ __launch_bounds__(256) void resample_v4_kernel(View s, View d, const int* start4, const int* pk4) {
+    const int rowbytes = d.w * d.c;                         // multiple of 16 (host-checked)
+    const int nchunks = rowbytes >> 4;
+    const int ck = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y, f = blockIdx.z;
+    if (ck >= nchunks) return;
+    const int y0 = start4[g];
+    const int* k = pk4 + (int64_t)g * 4 * KU;
+    const int nrows = min(4, d.h - 4 * g);
+    int acc[4][16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 1 << (PRECISION_BITS - 1);
+    const u8* sp = s.row(f, y0) + (ck << 4);
+#pragma unroll
+    for (int t = 0; t < KU; ++t) {
+        const uint4 q = *(const uint4*)(sp + (int64_t)t * s.rs);     // window rows lie inside the image (host-clamped)
+        const u32 w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = k[j * KU + t];
+            if (c != 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][e] += mul24((int)((w[e >> 2] >> (8 * (e & 3))) & 0xffu), c);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < nrows) {
+            u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e >> 2] |= (u32)clip8(acc[j][e]) << (8 * (e & 3));
+            *(uint4*)(d.row(f, 4 * g + j) + (ck << 4)) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 static inline unsigned grid_for(int64_t total) {
     int64_t blocks = (total + 255) / 256;
     return (unsigned)(blocks > 16384 ? 16384 : (blocks < 1 ? 1 : blocks));
@@ -432,6 +483,12 @@ static bool v_fast_ok(const imgxf_lanczos_plan* p, const View& s, const View& d)
 }
 
 static int launch_v_fast(const imgxf_lanczos_plan* p, const View& s, const View& d, hipStream_t st) {
+    static const bool no_v4 = getenv("IMGXF_LANCZOS_NO_V4") != nullptr;
+    if (p->ku4 == 12 && !no_v4) {
+        dim3 grid4((unsigned)(((d.rowbytes() >> 4) + 255) / 256), (unsigned)((d.h + 3) / 4), (unsigned)d.n);
+        hipLaunchKernelGGL((resample_v4_kernel<12>), grid4, dim3(256), 0, st, s, d, p->d_start4_y, p->d_pk4_y);
+        return launch_status();
+    }
     dim3 grid((unsigned)(((d.rowbytes() >> 4) + 255) / 256), (unsigned)d.h, (unsigned)d.n);
     hipLaunchKernelGGL(resample_v_fast_kernel, grid, dim3(256), 0, st, s, d, p->d_start_y, p->d_pk_y, p->kpy);
     return launch_status();
@@ -509,6 +566,31 @@ IMGXF_API int imgxf_resample_plan_create(imgxf_lanczos_plan** plan, int in_h, in
             build_padded(in_h, out_h, p->ksy, kp, b, k, st, pk);
             p->kpy = kp;
             if ((rc = upload(st, &p->d_start_y)) == IMGXF_OK) rc = upload(pk, &p->d_pk_y);
+            // 4-row groups: union window of KU = 12 rows when every group's windows fit it
+            constexpr int KU = 12;
+            if (rc == IMGXF_OK && in_h >= KU) {
+                const int ng = (out_h + 3) / 4;
+                std::vector<int> st4(ng, 0), pk4((size_t)ng * 4 * KU, 0);
+                bool fits = true;
+                for (int g = 0; g < ng && fits; ++g) {
+                    int lo = b[2 * (4 * g)], hi = 0;
+                    for (int j = 0; j < 4 && 4 * g + j < out_h; ++j) {
+                        lo = std::min(lo, b[2 * (4 * g + j)]);
+                        hi = std::max(hi, b[2 * (4 * g + j)] + b[2 * (4 * g + j) + 1]);
+                    }
+                    if (hi - lo > KU) { fits = false; break; }
+                    const int base = std::min(lo, in_h - KU);
+                    st4[g] = base;
+                    for (int j = 0; j < 4 && 4 * g + j < out_h; ++j) {
+                        const int yy = 4 * g + j, xmin = b[2 * yy], cnt = b[2 * yy + 1];
+                        for (int x = 0; x < cnt; ++x) pk4[((size_t)g * 4 + j) * KU + (xmin - base) + x] = k[(size_t)yy * p->ksy + x];
+                    }
+                }
+                if (fits) {
+                    p->ku4 = KU;
+                    if ((rc = upload(st4, &p->d_start4_y)) == IMGXF_OK) rc = upload(pk4, &p->d_pk4_y);
+                }
+            }
         }
     }
     if (rc == IMGXF_OK && p->need_h && p->need_v) {
@@ -530,6 +612,8 @@ IMGXF_API int imgxf_lanczos_plan_destroy(imgxf_lanczos_plan* p) {
     if (p->d_pk_x) (void)hipFree(p->d_pk_x);
     if (p->d_start_y) (void)hipFree(p->d_start_y);
     if (p->d_pk_y) (void)hipFree(p->d_pk_y);
+    if (p->d_start4_y) (void)hipFree(p->d_start4_y);
+    if (p->d_pk4_y) (void)hipFree(p->d_pk4_y);
     if (p->d_tmp) (void)hipFree(p->d_tmp);
     delete p;
     return IMGXF_OK;

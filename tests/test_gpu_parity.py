@@ -424,7 +424,7 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("knob", ["IMGXF_NO_MARCH", "IMGXF_AFFINE_NO_LDS", "IMGXF_AFFINE_NO_DMA", "IMGXF_LANCZOS_SLOW", "IMGXF_LANCZOS_NO_LDS", "IMGXF_AFFINE_NO_TALL"])
+@pytest.mark.parametrize("knob", ["IMGXF_NO_MARCH", "IMGXF_AFFINE_NO_LDS", "IMGXF_AFFINE_NO_DMA", "IMGXF_LANCZOS_SLOW", "IMGXF_LANCZOS_NO_LDS", "IMGXF_LANCZOS_NO_V4", "IMGXF_AFFINE_NO_TALL"])
 def test_general_kernels_behind_the_tuning_knobs(device, knob):
     """The environment knobs route aligned inputs to the general kernels (LDS-tiled separable
     filter, global-gather affine, dword-staged nearest, per-tap Lanczos); each must hold the
