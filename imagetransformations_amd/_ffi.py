@@ -52,6 +52,8 @@ SIGNATURES = {
     "imgxf_affine_scale_nearest_u8": [_VP, _VP, _D, _U8, C.c_void_p, C.c_size_t, C.c_void_p],
     "imgxf_lanczos_plan_create": [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     "imgxf_resample_plan_create": [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
+    "imgxf_resample_plan_create_window": [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int],
     "imgxf_lanczos_plan_destroy": [C.c_void_p],
     "imgxf_resize_lanczos_u8": [C.c_void_p, _VP, _VP, C.c_void_p],
     "imgxf_rgb2l_u8": [_VP, _VP, C.c_void_p],

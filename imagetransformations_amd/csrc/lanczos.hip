@@ -33,6 +33,10 @@ struct imgxf_lanczos_plan {
     int* d_pk4_y;            // [ceil(out_h/4)][4][ku4]
     uint8_t* d_tmp;          // [max_frames][in_h][out_w][c], only when both passes run
     int need_h, need_v;
+    // output window (crop fused into the resize): the plan produces rows [wy, wy+wh) x columns
+    // [wx, wx+ww) of the virtual out_h x out_w result; the H pass then only filters source rows
+    // [ry0, ry0+rh), the ones the window's vertical taps touch
+    int wx, wy, ww, wh, ry0, rh;
 };
 
 namespace imgxf {
@@ -523,21 +527,56 @@ IMGXF_API int imgxf_lanczos_plan_create(imgxf_lanczos_plan** plan, int in_h, int
 
 IMGXF_API int imgxf_resample_plan_create(imgxf_lanczos_plan** plan, int in_h, int in_w, int out_h,
                                          int out_w, int c, int max_frames, int filter) {
+    return imgxf_resample_plan_create_window(plan, in_h, in_w, out_h, out_w, c, max_frames, filter, 0, 0, out_w, out_h);
+}
+
+// keep rows [first, first + count) of a (bounds, coefficients) table pair
+static void slice_tables(std::vector<int>& b, std::vector<int>& k, int ksize, int first, int count) {
+    std::vector<int> b2(b.begin() + 2 * (size_t)first, b.begin() + 2 * (size_t)(first + count));
+    std::vector<int> k2(k.begin() + (size_t)first * ksize, k.begin() + (size_t)(first + count) * ksize);
+    b.swap(b2); k.swap(k2);
+}
+
+IMGXF_API int imgxf_resample_plan_create_window(imgxf_lanczos_plan** plan, int in_h_full, int in_w, int out_h_full,
+                                                int out_w_full, int c, int max_frames, int filter,
+                                                int wx, int wy, int ww, int wh) {
     if (!plan) return IMGXF_ERR_NULL;
     *plan = nullptr;
-    if (in_h < 1 || in_w < 1 || out_h < 1 || out_w < 1 || max_frames < 1) return IMGXF_ERR_ARG;
+    if (in_h_full < 1 || in_w < 1 || out_h_full < 1 || out_w_full < 1 || max_frames < 1) return IMGXF_ERR_ARG;
     if (filter < IMGXF_RESAMPLE_LANCZOS || filter > IMGXF_RESAMPLE_HAMMING) return IMGXF_ERR_ARG;
     if (c != 1 && c != 3 && c != 4) return IMGXF_ERR_UNSUPPORTED;
+    if (wx < 0 || wy < 0 || ww < 1 || wh < 1 || wx + ww > out_w_full || wy + wh > out_h_full) return IMGXF_ERR_ARG;
+    const bool windowed = wx != 0 || wy != 0 || ww != out_w_full || wh != out_h_full;
+    // a window needs both passes (a skipped pass would have to become a crop)
+    if (windowed && (out_w_full == in_w || out_h_full == in_h_full)) return IMGXF_ERR_UNSUPPORTED;
     imgxf_lanczos_plan* p = new imgxf_lanczos_plan();
     memset(p, 0, sizeof(*p));
-    p->in_h = in_h; p->in_w = in_w; p->out_h = out_h; p->out_w = out_w; p->c = c;
+    p->in_h = in_h_full; p->in_w = in_w; p->c = c;
+    p->out_h = wh; p->out_w = ww;              // what the resize call writes
+    p->wx = wx; p->wy = wy; p->ww = ww; p->wh = wh; p->ry0 = 0; p->rh = in_h_full;
     p->max_frames = max_frames;
-    p->need_h = out_w != in_w;   // ImagingResample: a pass is skipped when the size is unchanged
-    p->need_v = out_h != in_h;
+    p->need_h = out_w_full != in_w;   // ImagingResample: a pass is skipped when the size is unchanged
+    p->need_v = out_h_full != in_h_full;
     int rc = IMGXF_OK;
+    // vertical coefficients first: they decide which source rows the horizontal pass must produce
+    std::vector<int> by, ky;
+    int in_h = in_h_full;                       // rows the vertical pass sees (the H pass output)
+    const int out_h = wh, out_w = ww;
+    if (p->need_v) {
+        p->ksy = build_coeffs(in_h_full, out_h_full, filter, by, ky);
+        slice_tables(by, ky, p->ksy, wy, wh);
+        if (windowed) {
+            int lo = by[0], hi = 0;
+            for (int i = 0; i < wh; ++i) { lo = std::min(lo, by[2 * i]); hi = std::max(hi, by[2 * i] + by[2 * i + 1]); }
+            p->ry0 = lo; p->rh = hi - lo;
+            for (int i = 0; i < wh; ++i) by[2 * i] -= lo;
+            in_h = p->rh;
+        }
+    }
     if (p->need_h) {
         std::vector<int> b, k;
-        p->ksx = build_coeffs(in_w, out_w, filter, b, k);
+        p->ksx = build_coeffs(in_w, out_w_full, filter, b, k);
+        slice_tables(b, k, p->ksx, wx, ww);
         if ((rc = upload(b, &p->d_bounds_x)) == IMGXF_OK) rc = upload(k, &p->d_kk_x);
         const int kp = p->ksx <= 8 ? 8 : (p->ksx <= 12 ? 12 : (p->ksx <= 16 ? 16 : 0));
         if (rc == IMGXF_OK && c == 3 && kp && in_w >= kp) {
@@ -557,8 +596,8 @@ IMGXF_API int imgxf_resample_plan_create(imgxf_lanczos_plan** plan, int in_h, in
         }
     }
     if (rc == IMGXF_OK && p->need_v) {
-        std::vector<int> b, k;
-        p->ksy = build_coeffs(in_h, out_h, filter, b, k);
+        std::vector<int>& b = by;
+        std::vector<int>& k = ky;
         if ((rc = upload(b, &p->d_bounds_y)) == IMGXF_OK) rc = upload(k, &p->d_kk_y);
         const int kp = p->ksy;
         if (rc == IMGXF_OK && in_h >= kp) {
@@ -594,7 +633,7 @@ IMGXF_API int imgxf_resample_plan_create(imgxf_lanczos_plan** plan, int in_h, in
         }
     }
     if (rc == IMGXF_OK && p->need_h && p->need_v) {
-        hipError_t e = hipMalloc((void**)&p->d_tmp, (size_t)max_frames * in_h * out_w * c);
+        hipError_t e = hipMalloc((void**)&p->d_tmp, (size_t)max_frames * p->rh * out_w * c);
         if (e != hipSuccess) rc = (int)e;
     }
     if (rc != IMGXF_OK) { imgxf_lanczos_plan_destroy(p); return rc; }
@@ -648,9 +687,11 @@ IMGXF_API int imgxf_resize_lanczos_u8(const imgxf_lanczos_plan* p, const imgxf_v
     if (p->need_h && !p->need_v) return run_h(s, d);
     View mid = s;
     if (p->need_h) {
-        mid.p = p->d_tmp; mid.n = s.n; mid.h = p->in_h; mid.w = p->out_w; mid.c = p->c;
-        mid.rs = (int64_t)p->out_w * p->c; mid.fs = mid.rs * p->in_h;
-        IMGXF_CHECK(run_h(s, mid));
+        View sub = s;                                  // the source rows the window's vertical taps touch
+        sub.p = s.p + (int64_t)p->ry0 * s.rs; sub.h = p->rh;
+        mid.p = p->d_tmp; mid.n = s.n; mid.h = p->rh; mid.w = p->out_w; mid.c = p->c;
+        mid.rs = (int64_t)p->out_w * p->c; mid.fs = mid.rs * p->rh;
+        IMGXF_CHECK(run_h(sub, mid));
     }
     if (!slow && v_fast_ok(p, mid, d)) return launch_v_fast(p, mid, d, st);
     const int64_t total = (int64_t)d.n * d.h * d.rowbytes();

@@ -227,8 +227,8 @@ class _PlanCache:
     def __init__(self):
         self._plans: dict = {}
 
-    def get(self, in_h, in_w, out_h, out_w, c, n, device_index, resample=1):
-        key = (in_h, in_w, out_h, out_w, c, device_index, resample)
+    def get(self, in_h, in_w, out_h, out_w, c, n, device_index, resample=1, window=None):
+        key = (in_h, in_w, out_h, out_w, c, device_index, resample, window)
         ent = self._plans.get(key)
         if ent is not None and ent[1] >= n:
             return ent[0]
@@ -237,7 +237,11 @@ class _PlanCache:
         import ctypes
         handle = ctypes.c_void_p()
         with torch.cuda.device(device_index):
-            F.call("imgxf_resample_plan_create", ctypes.byref(handle), in_h, in_w, out_h, out_w, c, n, resample)
+            if window is None:
+                F.call("imgxf_resample_plan_create", ctypes.byref(handle), in_h, in_w, out_h, out_w, c, n, resample)
+            else:
+                F.call("imgxf_resample_plan_create_window", ctypes.byref(handle), in_h, in_w, out_h, out_w, c, n,
+                       resample, *window)
         self._plans[key] = (handle, n)
         return handle
 
@@ -255,10 +259,12 @@ def resize_lanczos(t: torch.Tensor, size: tuple[int, int]) -> torch.Tensor:
     return resize(t, size, RESAMPLE_LANCZOS)
 
 
-def resize(t: torch.Tensor, size: tuple[int, int], resample: int = RESAMPLE_BICUBIC) -> torch.Tensor:
+def resize(t: torch.Tensor, size: tuple[int, int], resample: int = RESAMPLE_BICUBIC,
+           out: torch.Tensor | None = None) -> torch.Tensor:
     """Image.resize(size, resample) for the convolution filters of Resample.c (Pillow's
     Resampling values: LANCZOS=1, BILINEAR=2, BICUBIC=3 (Image.resize's default), BOX=4,
-    HAMMING=5); NEAREST resize is an affine scale (`affine`)."""
+    HAMMING=5); NEAREST resize is an affine scale (`affine`).  `out`: optional destination of
+    the right shape — may be a strided window of a larger tensor (e.g. a paste target)."""
     if resample not in (RESAMPLE_LANCZOS, RESAMPLE_BILINEAR, RESAMPLE_BICUBIC, RESAMPLE_BOX, RESAMPLE_HAMMING):
         raise ValueError(f"Unknown resampling filter ({resample})")
     t = _check_u8(t)
@@ -267,10 +273,37 @@ def resize(t: torch.Tensor, size: tuple[int, int], resample: int = RESAMPLE_BICU
     if nw < 1 or nh < 1:
         raise ValueError("height and width must be > 0")   # Pillow's message
     n = t.shape[0] if t.dim() == 4 else 1
-    out = _like(t, nh, nw)
+    if out is None:
+        out = _like(t, nh, nw)
+    else:
+        want = [nh, nw] if t.dim() == 2 else list(t.shape[:-3]) + [nh, nw, t.shape[-1]]
+        if out.dtype != torch.uint8 or out.device != t.device or tuple(out.shape) != tuple(want):
+            raise ValueError(f"out must be a uint8 tensor of shape {tuple(want)} on {t.device}")
     if n == 0:
         return out
     plan = _plans.get(h, w, nh, nw, c, n, t.device.index or 0, int(resample))
+    F.call("imgxf_resize_lanczos_u8", plan, F.vp(F.view_of(t)), F.vp(F.view_of(out)), _stream())
+    return out
+
+
+def resize_crop(t: torch.Tensor, size: tuple[int, int], box: tuple[int, int, int, int],
+                resample: int = RESAMPLE_LANCZOS) -> torch.Tensor:
+    """img.resize(size, resample).crop(box) without computing the cropped-away pixels: only the
+    window's columns are filtered horizontally (and only the source rows its vertical taps
+    touch), only its rows vertically.  Same coefficients, bit-identical to resize + crop."""
+    t = _check_u8(t)
+    h, w, c = _hwc(t)
+    nw, nh = int(size[0]), int(size[1])
+    l, tp, r, b = (int(v) for v in box)
+    if not (0 <= l < r <= nw and 0 <= tp < b <= nh):
+        raise ValueError("crop box must lie inside the resized image")
+    if nw == w or nh == h:
+        return crop(resize(t, size, resample), box)
+    n = t.shape[0] if t.dim() == 4 else 1
+    out = _like(t, b - tp, r - l)
+    if n == 0:
+        return out
+    plan = _plans.get(h, w, nh, nw, c, n, t.device.index or 0, int(resample), (l, tp, r - l, b - tp))
     F.call("imgxf_resize_lanczos_u8", plan, F.vp(F.view_of(t)), F.vp(F.view_of(out)), _stream())
     return out
 

@@ -71,17 +71,20 @@ def _scale_t(t: torch.Tensor, scale_factor: float) -> torch.Tensor:
     height, width = _hw(t)
     new_width = int(width * scale_factor)
     new_height = int(height * scale_factor)
-    scaled = ops.resize_lanczos(t, (new_width, new_height))
     if scale_factor > 1.0:
+        # resize + centre crop in one pass over the pixels that survive the crop
         left = (new_width - width) // 2
         top = (new_height - height) // 2
-        scaled = ops.crop(scaled, (left, top, left + width, top + height))
-    elif scale_factor < 1.0:
-        canvas = ops.new(scaled, height, width, (0, 0, 0))
-        ops.copy_rect(scaled, canvas, 0, 0, (width - new_width) // 2, (height - new_height) // 2,
-                      new_width, new_height)
-        scaled = canvas
-    return scaled
+        return ops.resize_crop(t, (new_width, new_height), (left, top, left + width, top + height))
+    if scale_factor < 1.0 and new_width >= 1 and new_height >= 1:
+        # resize straight into its place on the black canvas (the paste at :188-194)
+        canvas = ops.new(t, height, width, (0, 0, 0))
+        left, top = (width - new_width) // 2, (height - new_height) // 2
+        window = canvas[..., top:top + new_height, left:left + new_width, :] if t.dim() >= 3 else \
+            canvas[top:top + new_height, left:left + new_width]
+        ops.resize(t, (new_width, new_height), ops.RESAMPLE_LANCZOS, out=window)
+        return canvas
+    return ops.resize_lanczos(t, (new_width, new_height))
 
 
 def apply_scale(img: Image.Image, scale_factor: float) -> Image.Image:

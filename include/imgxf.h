@@ -130,6 +130,13 @@ enum { IMGXF_RESAMPLE_LANCZOS = 1, IMGXF_RESAMPLE_BILINEAR = 2, IMGXF_RESAMPLE_B
        IMGXF_RESAMPLE_BOX = 4, IMGXF_RESAMPLE_HAMMING = 5 };
 int imgxf_resample_plan_create(imgxf_lanczos_plan** plan, int in_h, int in_w, int out_h,
                                int out_w, int c, int max_frames, int filter);
+/* Resize + crop in one: the plan produces only rows [wy, wy+wh) x columns [wx, wx+ww) of the
+ * out_h x out_w result (dst of the resize call is wh x ww) and filters only the source rows and
+ * output columns that window needs — apply_scale's centre crop (transformation.py:182-187)
+ * without computing the pixels it throws away.  Needs out_w != in_w and out_h != in_h. */
+int imgxf_resample_plan_create_window(imgxf_lanczos_plan** plan, int in_h, int in_w, int out_h,
+                                      int out_w, int c, int max_frames, int filter,
+                                      int wx, int wy, int ww, int wh);
 
 /* ---- a6: elementwise colour maps ------------------------------------------------------*/
 /* Pillow convert('L') transformation.py:336: (19595R+38470G+7471B+0x8000)>>16. src c in {3,4}, dst c==1 */

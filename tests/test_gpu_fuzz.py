@@ -126,3 +126,26 @@ def test_bilinear_special_matrices(device, hw):
         batch = dev(np.stack([a, a[::-1].copy()]), device)
         got2 = host(ops.affine(batch, m, size, ops.BILINEAR, (1, 2, 3), precise=True))
         assert np.array_equal(got2[1], O.affine_bilinear(a[::-1].copy(), size, m, fill=(1, 2, 3))), (hw, m)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_resize_crop_equals_resize_then_crop(device, seed):
+    """ops.resize_crop (window fused into the resample plan) == Pillow's resize followed by crop,
+    for every filter, aligned and unaligned widths, windows touching every border."""
+    from imagetransformations_amd import ops
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3000 + seed)
+    h = int(rng.integers(30, 120))
+    w = int(rng.integers(2, 30)) * 16 if seed % 2 == 0 else int(rng.integers(30, 300))
+    a = rnd_image(rng, h, w)
+    t = dev(np.stack([a, a[::-1].copy()]), device)
+    for sc in (1.1, 1.3, 0.8, 1.7):
+        nw, nh = int(w * sc), int(h * sc)
+        boxes = [((nw - w) // 2, (nh - h) // 2, (nw - w) // 2 + w, (nh - h) // 2 + h)] if sc > 1 else []
+        boxes += [(0, 0, max(1, nw // 2), max(1, nh // 3)), (nw // 3, nh // 2, nw, nh), (nw - 1, nh - 1, nw, nh), (0, 0, nw, nh)]
+        for box in boxes:
+            for flt in (1, 3, 2):
+                want0 = np.asarray(Image.fromarray(a).resize((nw, nh), flt).crop(box))
+                want1 = np.asarray(Image.fromarray(a[::-1].copy()).resize((nw, nh), flt).crop(box))
+                got = host(ops.resize_crop(t, (nw, nh), box, flt))
+                assert np.array_equal(got[0], want0) and np.array_equal(got[1], want1), (h, w, sc, box, flt)
