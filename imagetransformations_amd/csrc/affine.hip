@@ -1147,6 +1147,60 @@ static int launch_affine_filter(int filter, const View& s, const View& d, const 
     return launch_status();
 }
 
+// Tall interior tiles: `affine_bilinear_lds_interior_kernel<.., BHT>` over every 32 x BHT tile (the
+// ones that are not interior leave at once) and `affine_bilinear_lds_list_kernel` over the host's
+// list of those that are not.  Returns BILINEAR_TALL_NOT_TAKEN when the taller tile's source box
+// does not fit PITCH x MAXROWS of LDS or the list does not fit the launch arguments.
+constexpr int BILINEAR_TALL_NOT_TAKEN = 1 << 30;
+
+template <int BHT, int PITCH, int MAXROWS>
+static int launch_bilinear_tall(const View& s, const View& d, const AffineParams& P, const View& dbg, const double* m,
+                                int bw, int bh, int ntx, bool pr, hipStream_t st) {
+    const int bwt = (int)ceil(fabs(m[0]) * 31 + fabs(m[1]) * (BHT - 1)) + 4;
+    const int bht = (int)ceil(fabs(m[3]) * 31 + fabs(m[4]) * (BHT - 1)) + 4;
+    const int ntyt = (d.h + BHT - 1) / BHT;
+    if (bwt > PITCH || bht > MAXROWS || bw > PITCH || (int64_t)ntx * ntyt * ntx >= ((int64_t)1 << 32))
+        return BILINEAR_TALL_NOT_TAKEN;
+    // the kernel's interior test (bilinear_tile<.., BHT, true>) with the same integers
+    TileList list;
+    list.n = 0;
+    const int64_t ax = 31 * P.q0, bx = (BHT - 1) * P.q1, ay = 31 * P.q3, by = (BHT - 1) * P.q4;
+    const int64_t xlo_o = std::min(ax, (int64_t)0) + std::min(bx, (int64_t)0), xhi_o = std::max(ax, (int64_t)0) + std::max(bx, (int64_t)0);
+    const int64_t ylo_o = std::min(ay, (int64_t)0) + std::min(by, (int64_t)0), yhi_o = std::max(ay, (int64_t)0) + std::max(by, (int64_t)0);
+    for (int ty = 0; ty < ntyt && list.n <= BILINEAR_LIST_MAX; ++ty)
+        for (int tx = 0; tx < ntx; ++tx) {
+            const int64_t XT = P.x00 + (int64_t)(tx * 32) * P.q0 + (int64_t)(ty * BHT) * P.q1;
+            const int64_t YT = P.y00 + (int64_t)(tx * 32) * P.q3 + (int64_t)(ty * BHT) * P.q4;
+            const bool clean = (int)((XT + xlo_o) >> 40) >= 0 && (int)((YT + ylo_o) >> 40) >= 0 &&
+                               (int)((XT + xhi_o) >> 40) + 1 <= s.w - 1 && (int)((YT + yhi_o) >> 40) + 1 <= s.h - 1 &&
+                               tx * 32 + 32 <= d.w && ty * BHT + BHT <= d.h;
+            if (!clean) {
+                if (list.n < BILINEAR_LIST_MAX) list.idx[list.n] = (u32)(ty * ntx + tx);
+                ++list.n;
+            }
+        }
+    if (list.n > BILINEAR_LIST_MAX) return BILINEAR_TALL_NOT_TAKEN;
+    const bool want_f32 = dbg.p != nullptr;
+    if (list.n < ntx * ntyt) {                       // at least one interior tile
+        const dim3 grid((unsigned)(ntx * ntyt), (unsigned)d.n);
+        const size_t lds = (size_t)PITCH * bht * 4 + 16;
+        if (pr && want_f32) hipLaunchKernelGGL((affine_bilinear_lds_interior_kernel<true, PITCH, true, BHT>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, ntyt);
+        else if (pr) hipLaunchKernelGGL((affine_bilinear_lds_interior_kernel<true, PITCH, false, BHT>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, ntyt);
+        else if (want_f32) hipLaunchKernelGGL((affine_bilinear_lds_interior_kernel<false, PITCH, true, BHT>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, ntyt);
+        else hipLaunchKernelGGL((affine_bilinear_lds_interior_kernel<false, PITCH, false, BHT>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, ntyt);
+        IMGXF_CHECK(launch_status());
+    }
+    if (list.n > 0) {
+        const dim3 grid((unsigned)((BHT / 32) * list.n), (unsigned)d.n);
+        const size_t lds = (size_t)PITCH * bh * 4 + 16;
+        if (pr && want_f32) hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<true, PITCH, true, BHT>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, list);
+        else if (pr) hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<true, PITCH, false, BHT>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, list);
+        else if (want_f32) hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<false, PITCH, true, BHT>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, list);
+        else hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<false, PITCH, false, BHT>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, list);
+    }
+    return launch_status();
+}
+
 int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, int filter,
                const uint8_t* fill, int precise, const imgxf_view* dbg_f32, void* stream) {
     IMGXF_CHECK(check_view(src));
@@ -1262,63 +1316,13 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
         IMGXF_LDS_LAUNCH(affine_bilinear_lds_kernel, PITCH, grid, nty, lds);                       \
         return launch_status();                                                                    \
     } while (0)
-                // tall interior tiles (32x64, 8 pixels per lane) + a host-built list of the
-                // others, when the taller tile's source box still fits LDS and the list fits the launch arguments
+                // interior tiles as 32x64 (8 pixels per lane) + a host-built list of the others, when
+                // the geometry qualifies
                 static const bool no_tall = getenv("IMGXF_AFFINE_NO_TALL") != nullptr;
-#define IMGXF_TALL(BHT, PITCH, MAXROWS)                                                            \
-    do {                                                                                           \
-        const int bwt = (int)ceil(fabs(m[0]) * 31 + fabs(m[1]) * (BHT - 1)) + 4;                   \
-        const int bht = (int)ceil(fabs(m[3]) * 31 + fabs(m[4]) * (BHT - 1)) + 4;                   \
-        const int ntyt = (d.h + BHT - 1) / BHT;                                                    \
-        if (bwt <= PITCH && bht <= MAXROWS && bw <= PITCH && (int64_t)ntx * ntyt * ntx < ((int64_t)1 << 32)) { \
-            TileList list;                                                                         \
-            list.n = 0;                                                                            \
-            /* the kernel's interior test (bilinear_tile<.., BHT, true>), same integers */         \
-            const int64_t ax = 31 * P.q0, bx = (BHT - 1) * P.q1, ay = 31 * P.q3, by = (BHT - 1) * P.q4; \
-            const int64_t xlo_o = std::min(ax, (int64_t)0) + std::min(bx, (int64_t)0), xhi_o = std::max(ax, (int64_t)0) + std::max(bx, (int64_t)0); \
-            const int64_t ylo_o = std::min(ay, (int64_t)0) + std::min(by, (int64_t)0), yhi_o = std::max(ay, (int64_t)0) + std::max(by, (int64_t)0); \
-            for (int ty = 0; ty < ntyt && list.n <= BILINEAR_LIST_MAX; ++ty)                       \
-                for (int tx = 0; tx < ntx; ++tx) {                                                 \
-                    const int64_t XT = P.x00 + (int64_t)(tx * 32) * P.q0 + (int64_t)(ty * BHT) * P.q1; \
-                    const int64_t YT = P.y00 + (int64_t)(tx * 32) * P.q3 + (int64_t)(ty * BHT) * P.q4; \
-                    const bool clean = (int)((XT + xlo_o) >> 40) >= 0 && (int)((YT + ylo_o) >> 40) >= 0 && \
-                                       (int)((XT + xhi_o) >> 40) + 1 <= s.w - 1 && (int)((YT + yhi_o) >> 40) + 1 <= s.h - 1 && \
-                                       tx * 32 + 32 <= d.w && ty * BHT + BHT <= d.h;               \
-                    if (!clean) {                                                                  \
-                        if (list.n < BILINEAR_LIST_MAX) list.idx[list.n] = (u32)(ty * ntx + tx);   \
-                        ++list.n;                                                                  \
-                    }                                                                              \
-                }                                                                                  \
-            if (list.n <= BILINEAR_LIST_MAX) {                                                     \
-                if (list.n < ntx * ntyt) {           /* at least one interior tile */              \
-                    dim3 gridt((unsigned)(ntx * ntyt), (unsigned)d.n);                             \
-                    const size_t ldst = (size_t)PITCH * bht * 4 + 16;                              \
-                    if (dbg.p) {                                                                   \
-                        if (pr) hipLaunchKernelGGL((affine_bilinear_lds_interior_kernel<true, PITCH, true, BHT>), gridt, dim3(256), ldst, st, s, d, P, dbg, ntx, ntyt); \
-                        else hipLaunchKernelGGL((affine_bilinear_lds_interior_kernel<false, PITCH, true, BHT>), gridt, dim3(256), ldst, st, s, d, P, dbg, ntx, ntyt); \
-                    } else {                                                                       \
-                        if (pr) hipLaunchKernelGGL((affine_bilinear_lds_interior_kernel<true, PITCH, false, BHT>), gridt, dim3(256), ldst, st, s, d, P, dbg, ntx, ntyt); \
-                        else hipLaunchKernelGGL((affine_bilinear_lds_interior_kernel<false, PITCH, false, BHT>), gridt, dim3(256), ldst, st, s, d, P, dbg, ntx, ntyt); \
-                    }                                                                              \
-                    IMGXF_CHECK(launch_status());                                                  \
-                }                                                                                  \
-                if (list.n > 0) {                                                                  \
-                    dim3 gridl((unsigned)((BHT / 32) * list.n), (unsigned)d.n);                    \
-                    const size_t lds = (size_t)PITCH * bh * 4 + 16;                                \
-                    if (dbg.p) {                                                                   \
-                        if (pr) hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<true, PITCH, true, BHT>), gridl, dim3(256), lds, st, s, d, P, dbg, ntx, list); \
-                        else hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<false, PITCH, true, BHT>), gridl, dim3(256), lds, st, s, d, P, dbg, ntx, list); \
-                    } else {                                                                       \
-                        if (pr) hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<true, PITCH, false, BHT>), gridl, dim3(256), lds, st, s, d, P, dbg, ntx, list); \
-                        else hipLaunchKernelGGL((affine_bilinear_lds_list_kernel<false, PITCH, false, BHT>), gridl, dim3(256), lds, st, s, d, P, dbg, ntx, list); \
-                    }                                                                              \
-                }                                                                                  \
-                return launch_status();                                                            \
-            }                                                                                      \
-        }                                                                                          \
-    } while (0)
-                if (!no_tall) IMGXF_TALL(64, 49, 64);     // (32x128 tiles measured slower: 1.18 vs 1.08 ms)
-#undef IMGXF_TALL
+                if (!no_tall) {
+                    const int rc = launch_bilinear_tall<64, 49, 64>(s, d, P, dbg, m, bw, bh, ntx, pr, st);
+                    if (rc != BILINEAR_TALL_NOT_TAKEN) return rc;     // (32x128 tiles measured slower: 1.18 vs 1.08 ms)
+                }
                 if (bw <= 49) IMGXF_LDS(49);
                 if (bw <= 65) IMGXF_LDS(65);
                 IMGXF_LDS(97);
