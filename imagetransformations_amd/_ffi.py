@@ -48,6 +48,7 @@ SIGNATURES = {
     "imgxf_conv2d_u8": [_VP, _VP, _F, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "imgxf_sobel_u8": [_VP, _VP, C.c_int, C.c_void_p],
     "imgxf_rgb_sobel_mag_u8": [_VP, _VP, C.c_void_p],
+    "imgxf_rgb_sobel_u8": [_VP, _VP, C.c_int, C.c_void_p],
     "imgxf_affine_u8": [_VP, _VP, _D, C.c_int, _U8, C.c_int, _VP, C.c_void_p],
     "imgxf_affine_scale_nearest_u8": [_VP, _VP, _D, _U8, C.c_void_p, C.c_size_t, C.c_void_p],
     "imgxf_lanczos_plan_create": [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
@@ -62,6 +63,7 @@ SIGNATURES = {
     "imgxf_add_noise_u8": [_VP, _VP, _VP, C.c_void_p],
     "imgxf_permute_u8": [_VP, _VP, _I32, C.c_void_p],
     "imgxf_composite_u8": [_VP, _VP, _VP, _VP, C.c_void_p],
+    "imgxf_composite_const_u8": [_VP, _U8, _VP, _VP, C.c_void_p],
     "imgxf_add_noise_f64_u8": [_VP, _VP, _VP, C.c_void_p],
     "imgxf_shot_noise_u8": [_VP, C.c_double, _VP, C.c_void_p],
     "imgxf_impulse_noise_u8": [_VP, _VP, C.c_double, C.c_double, _VP, C.c_void_p],

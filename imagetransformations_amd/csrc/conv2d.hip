@@ -289,17 +289,26 @@ IMGXF_API int imgxf_sobel_u8(const imgxf_view* src, const imgxf_view* dst, int v
     return launch_status();
 }
 
-IMGXF_API int imgxf_rgb_sobel_mag_u8(const imgxf_view* src, const imgxf_view* dst, void* stream) {
+IMGXF_API int imgxf_rgb_sobel_u8(const imgxf_view* src, const imgxf_view* dst, int variant, void* stream) {
     IMGXF_CHECK(check_view(src));
     IMGXF_CHECK(check_view(dst));
     if (!same_nhw(src, dst) || src->c != 3 || dst->c != 1) return IMGXF_ERR_SHAPE;
+    if (variant < 0 || variant > 2) return IMGXF_ERR_ARG;
     if (empty_view(src)) return IMGXF_OK;
     const View s = make_view(src), d = make_view(dst);
     static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
-    if (!no_march && sobel_march_eligible(s, d, 3))
-        return launch_sobel_march<3, IMGXF_SOBEL_MAGNITUDE>(s, d, (hipStream_t)stream);
+    if (!no_march && sobel_march_eligible(s, d, 3)) {
+        switch (variant) {
+            case IMGXF_SOBEL_X_WRAP: return launch_sobel_march<3, IMGXF_SOBEL_X_WRAP>(s, d, (hipStream_t)stream);
+            case IMGXF_SOBEL_Y_WRAP: return launch_sobel_march<3, IMGXF_SOBEL_Y_WRAP>(s, d, (hipStream_t)stream);
+            default: return launch_sobel_march<3, IMGXF_SOBEL_MAGNITUDE>(s, d, (hipStream_t)stream);
+        }
+    }
     dim3 grid((unsigned)((s.w + 63) / 64), (unsigned)((s.h + 15) / 16), (unsigned)s.n);
-    hipLaunchKernelGGL((sobel_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, s, d,
-                       (int)IMGXF_SOBEL_MAGNITUDE);
+    hipLaunchKernelGGL((sobel_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, s, d, variant);
     return launch_status();
+}
+
+IMGXF_API int imgxf_rgb_sobel_mag_u8(const imgxf_view* src, const imgxf_view* dst, void* stream) {
+    return imgxf_rgb_sobel_u8(src, dst, IMGXF_SOBEL_MAGNITUDE, stream);
 }

@@ -265,6 +265,53 @@ __global__ __launch_bounds__(256) void composite_rgb16_kernel(View a, View b, Vi
     }
 }
 
+// same, im2 = one colour (Image.new(mode, size, colour) never materialised)
+__global__ __launch_bounds__(256) void composite_const_rgb16_kernel(View a, View m, View d, u32 c0, u32 c1, u32 c2) {
+    const int ngrp = d.w >> 4;
+    const int64_t total = (int64_t)d.n * d.h * ngrp;
+    const u32 cpat[3] = {c0, c1, c2};                     // the colour as 12 interleaved bytes (period 3 dwords)
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int g = (int)(t % ngrp);
+        const int64_t r = t / ngrp;
+        const int y = (int)(r % d.h), f = (int)(r / d.h);
+        const uint4 mq = *(const uint4*)(m.row(f, y) + g * 16);
+        const u32 mw[4] = {mq.x, mq.y, mq.z, mq.w};
+        const uint4* ap = (const uint4*)(a.row(f, y) + g * 48);
+        uint4* dp = (uint4*)(d.row(f, y) + g * 48);
+        u32 av[12], ov[12];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint4 qa = ap[k];
+            av[4 * k] = qa.x; av[4 * k + 1] = qa.y; av[4 * k + 2] = qa.z; av[4 * k + 3] = qa.w;
+        }
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {
+            const u32 mm = nonzero_bytes_to_ff(mw[p4]);
+            const u32 s0 = __builtin_amdgcn_perm(0, mm, 0x01000000u);
+            const u32 s1 = __builtin_amdgcn_perm(0, mm, 0x02020101u);
+            const u32 s2 = __builtin_amdgcn_perm(0, mm, 0x03030302u);
+            ov[3 * p4] = (av[3 * p4] & s0) | (cpat[0] & ~s0);
+            ov[3 * p4 + 1] = (av[3 * p4 + 1] & s1) | (cpat[1] & ~s1);
+            ov[3 * p4 + 2] = (av[3 * p4 + 2] & s2) | (cpat[2] & ~s2);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dp[k] = make_uint4(ov[4 * k], ov[4 * k + 1], ov[4 * k + 2], ov[4 * k + 3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void composite_const_kernel(View a, View m, View d, u32 colour) {
+    const int64_t total = (int64_t)d.n * d.h * d.w;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int x = (int)(t % d.w);
+        const int64_t r = t / d.w;
+        const int y = (int)(r % d.h), f = (int)(r / d.h);
+        const bool sel = m.row(f, y)[x] != 0;
+        const u8* src = a.row(f, y) + x * d.c;
+        u8* dp = d.row(f, y) + x * d.c;
+        for (int j = 0; j < d.c; ++j) dp[j] = sel ? src[j] : (u8)(colour >> (8 * j));
+    }
+}
+
 __global__ __launch_bounds__(256) void composite_kernel(View a, View b, View m, View d) {
     const int64_t total = (int64_t)d.n * d.h * d.w;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -628,5 +675,31 @@ IMGXF_API int imgxf_impulse_noise_u8(const imgxf_view* src, const imgxf_view* ma
     const View d = make_view(dst);
     hipLaunchKernelGGL(impulse_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0, (hipStream_t)stream,
                        make_view(src), make_view(mask_f64), d, lo, hi);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_composite_const_u8(const imgxf_view* im1, const uint8_t* colour, const imgxf_view* mask,
+                                       const imgxf_view* dst, void* stream) {
+    IMGXF_CHECK(check_view(im1));
+    IMGXF_CHECK(check_view(mask));
+    IMGXF_CHECK(check_view(dst));
+    if (!colour) return IMGXF_ERR_NULL;
+    if (!same_geometry(im1, dst) || !same_nhw(mask, dst) || mask->c != 1) return IMGXF_ERR_SHAPE;
+    if (empty_view(dst)) return IMGXF_OK;
+    const View d = make_view(dst), va = make_view(im1), vm = make_view(mask);
+    auto al16 = [](const View& v) { return ((((uintptr_t)v.p) | (uintptr_t)v.rs | (uintptr_t)v.fs) & 15) == 0; };
+    if (d.c == 3 && d.w % 16 == 0 && al16(va) && al16(vm) && al16(d)) {
+        uint8_t pat[12];
+        for (int i = 0; i < 12; ++i) pat[i] = colour[i % 3];
+        u32 c[3];
+        memcpy(c, pat, 12);
+        hipLaunchKernelGGL(composite_const_rgb16_kernel, dim3(grid_for((int64_t)d.n * d.h * (d.w >> 4))), dim3(256), 0,
+                           (hipStream_t)stream, va, vm, d, c[0], c[1], c[2]);
+        return launch_status();
+    }
+    u32 packed = 0;
+    for (int j = 0; j < d.c; ++j) packed |= (u32)colour[j] << (8 * j);
+    hipLaunchKernelGGL(composite_const_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0,
+                       (hipStream_t)stream, va, vm, d, packed);
     return launch_status();
 }

@@ -117,6 +117,14 @@ def rgb_sobel_magnitude(rgb: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def rgb_sobel(rgb: torch.Tensor, variant: int = F.SOBEL_X_WRAP) -> torch.Tensor:
+    """sobel(rgb2l(rgb), variant) without materialising L (transformation.py:336-339)."""
+    rgb = _check_u8(rgb)
+    out = _gray_like(rgb)
+    F.call("imgxf_rgb_sobel_u8", F.vp(F.view_of(rgb)), F.vp(_gray_view(out)), int(variant), _stream())
+    return out
+
+
 def _gray_view(t: torch.Tensor) -> F.View:
     """View of a single-channel tensor: [H,W], [H,W,1] or [N,H,W,1]."""
     if t.dim() >= 3 and t.shape[-1] != 1:
@@ -585,6 +593,16 @@ def composite(im1: torch.Tensor, im2: torch.Tensor, mask: torch.Tensor) -> torch
     im1, im2, mask = _check_u8(im1), _check_u8(im2), _check_u8(mask, "mask")
     out = torch.empty_like(im1, memory_format=torch.contiguous_format)
     F.call("imgxf_composite_u8", F.vp(F.view_of(im1)), F.vp(F.view_of(im2)), F.vp(_gray_view(mask)),
+           F.vp(F.view_of(out)), _stream())
+    return out
+
+
+def composite_const(im1: torch.Tensor, colour, mask: torch.Tensor) -> torch.Tensor:
+    """Image.composite(im1, Image.new(mode, size, colour), mask) without the constant image."""
+    im1, mask = _check_u8(im1), _check_u8(mask, "mask")
+    c = _hwc(im1)[2]
+    out = torch.empty_like(im1, memory_format=torch.contiguous_format)
+    F.call("imgxf_composite_const_u8", F.vp(F.view_of(im1)), _fill_bytes(colour, c), F.vp(_gray_view(mask)),
            F.vp(F.view_of(out)), _stream())
     return out
 

@@ -200,11 +200,10 @@ def _rgb_tensor(img: Image.Image) -> torch.Tensor:
 def apply_background_change(img: Image.Image, bg_color: Tuple[float, float, float]) -> Image.Image:
     bg_rgb = tuple(int(c * 255) for c in bg_color)
     rgb = _rgb_tensor(img)
-    background = ops.new(rgb, rgb.shape[0], rgb.shape[1], bg_rgb)
-    edges = ops.sobel(ops.rgb2l(rgb))                     # ndimage.sobel(gray) (:339)
+    edges = ops.rgb_sobel(rgb)                            # ndimage.sobel(img.convert('L')) (:336-339), L never stored
     edge_mask = ops.percentile_mask(edges, 70)            # edges > np.percentile(edges, 70)
     foreground = ops.dilate_cross(edge_mask, 3)           # binary_dilation(iterations=3)
-    return _download(ops.composite(rgb, background, foreground))
+    return _download(ops.composite_const(rgb, bg_rgb, foreground))   # Image.composite(img, Image.new(.., bg), mask)
 
 
 def apply_background_change_simple(img: Image.Image, bg_color: Tuple[float, float, float]) -> Image.Image:

@@ -91,6 +91,9 @@ int imgxf_conv2d_u8(const imgxf_view* src, const imgxf_view* dst, const float* k
 int imgxf_sobel_u8(const imgxf_view* src, const imgxf_view* dst, int variant, void* stream);
 /* Fused benchmark configs[2]: RGB(c==3) -> L (Pillow weights) -> Gx,Gy -> magnitude -> u8 (c==1). */
 int imgxf_rgb_sobel_mag_u8(const imgxf_view* src, const imgxf_view* dst, void* stream);
+/* Same fusion for every variant of imgxf_sobel_u8: RGB in, Pillow L on the fly, one u8 plane out
+ * (apply_background_change's edge image without materialising L, transformation.py:336-339). */
+int imgxf_rgb_sobel_u8(const imgxf_view* src, const imgxf_view* dst, int variant, void* stream);
 
 /* ---- a2/a2'/shear: Image.transform(size, AFFINE, m, resample, fillcolor) -------------
  * transformation.py:200 (rotate -> NEAREST), :217-224 (shear -> BICUBIC); BILINEAR is
@@ -160,6 +163,10 @@ int imgxf_permute_u8(const imgxf_view* src, const imgxf_view* dst, const int32_t
 /* Image.composite(im1, im2, mask) transformation.py:344 for a 0/255 mask (c==1): mask ? im1 : im2. */
 int imgxf_composite_u8(const imgxf_view* im1, const imgxf_view* im2, const imgxf_view* mask,
                        const imgxf_view* dst, void* stream);
+/* Image.composite(im1, Image.new(mode, size, colour), mask) without materialising the constant image
+ * (transformation.py:333,344). */
+int imgxf_composite_const_u8(const imgxf_view* im1, const uint8_t* colour, const imgxf_view* mask,
+                             const imgxf_view* dst, void* stream);
 
 /* ---- Image.filter(ImageFilter.Kernel((3,3), kernel, scale, offset)) — libImaging ImagingFilter3x3
  * (ImageFilter.SMOOTH behind ImageEnhance.Sharpness, cifar_image_transformations.py:95-99):

@@ -149,3 +149,20 @@ def test_resize_crop_equals_resize_then_crop(device, seed):
                 want1 = np.asarray(Image.fromarray(a[::-1].copy()).resize((nw, nh), flt).crop(box))
                 got = host(ops.resize_crop(t, (nw, nh), box, flt))
                 assert np.array_equal(got[0], want0) and np.array_equal(got[1], want1), (h, w, sc, box, flt)
+
+
+@pytest.mark.parametrize("hw", [(40, 64), (37, 61), (120, 1040)])
+def test_fused_background_stages(device, hw):
+    """rgb_sobel (L never stored) == sobel(rgb2l(.)) for all variants, composite_const ==
+    composite with a materialised constant image."""
+    from imagetransformations_amd import ops, _ffi
+    h, w = hw
+    rng = np.random.default_rng(h + w)
+    a = rnd_image(rng, h, w)
+    t = dev(np.stack([a, a[:, ::-1].copy()]), device)
+    for variant in (_ffi.SOBEL_X_WRAP, _ffi.SOBEL_Y_WRAP, _ffi.SOBEL_MAGNITUDE):
+        assert torch.equal(ops.rgb_sobel(t, variant), ops.sobel(ops.rgb2l(t), variant))
+    assert np.array_equal(host(ops.rgb_sobel(t))[0, ..., 0], O.sobel_scipy(O.rgb2l(a)))
+    mask = dev(((rng.random((2, h, w, 1)) < 0.3) * int(rng.integers(1, 256))).astype(np.uint8), device)
+    want = ops.composite(t, ops.new(t, h, w, (10, 200, 30)), mask)
+    assert torch.equal(ops.composite_const(t, (10, 200, 30), mask), want)

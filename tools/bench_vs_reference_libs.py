@@ -59,7 +59,7 @@ rows = [
     ("apply_shear 0.3 (transform BICUBIC)", lambda: ref_shear(0.3), lambda: T._shear_t(batch, 0.3)),
     ("apply_brightness 0.05 (ImageEnhance)", lambda: ImageEnhance.Brightness(img).enhance(1.05), lambda: ops.brightness(batch, 1.05)),
     ("apply_background_change (L, sobel, percentile, dilation, composite)", ref_background,
-     lambda: ops.composite(batch, ops.new(batch, H, W, (10, 200, 30)), ops.dilate_cross(ops.percentile_mask(ops.sobel(ops.rgb2l(batch)), 70), 3))),
+     lambda: ops.composite_const(batch, (10, 200, 30), ops.dilate_cross(ops.percentile_mask(ops.rgb_sobel(batch), 70), 3))),
     ("ImageOps.equalize (AugMix)", lambda: __import__("PIL.ImageOps", fromlist=["equalize"]).equalize(img), lambda: ops.equalize(batch)),
 ]
 print(f"{'transformation (library call the reference makes)':72s} {'CPU ms/frame':>12s} {'HIP ms/frame':>12s} {'ratio':>8s}")
