@@ -1012,14 +1012,88 @@ __global__ __launch_bounds__(256) void affine_nearest_dma_kernel(View s, View d,
 // sequence; so are pixels whose taps touch the left / right image border (clamped taps).
 // ---------------------------------------------------------------------------------------
 typedef uint32_t u32x2_sh __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t u32x4_ua __attribute__((ext_vector_type(4), aligned(1)));
 
-template <bool PRECISE>
+// libImaging's fp64 sequence for one pixel of a horizontal-only bicubic transform (row = source row
+// yi clamped, yok = the row passes the bounds test, a1y = m1 * (y + 0.5))
+__device__ __forceinline__ void shear_exact_px(const View& s, const AffineParams& P, const u8* row, bool yok, double a1y,
+                                               int x, u8 (&px)[3]) {
+    constexpr int C = 3;
+    const double xc = (double)x + 0.5;
+    double xin = __dadd_rn(__dadd_rn(__dmul_rn(P.m[0], xc), a1y), P.m[2]);
+    if (!(yok && xin >= 0.0 && xin < (double)s.w)) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) px[j] = P.fill[j];
+        return;
+    }
+    xin -= 0.5;
+    const double xfl = floor(xin);
+    const int xi = (int)xfl;
+    const double dx = xin - xfl;
+    int xs[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xs[t] = clampi(xi - 1 + t, 0, s.w - 1) * C;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const double v = cubic<PreciseArith>((double)row[xs[0] + j], (double)row[xs[1] + j],
+                                             (double)row[xs[2] + j], (double)row[xs[3] + j], dx);
+        px[j] = v <= 0.0 ? (u8)0 : (v >= 255.0 ? (u8)255 : (u8)(int)v);
+    }
+}
+
+// Unit-step rows, second pass: the few 4-pixel groups at both ends of the source row (taps
+// clamped at the image edge, or partly outside) that shear_bicubic_kernel<.., true> left out.
+// One lane per (row, candidate group); pixels inside the source are evaluated with the fp64
+// sequence and stored byte-wise.
+__global__ __launch_bounds__(256) void shear_edges_kernel(View s, View d, AffineParams P) {
+    constexpr int C = 3;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int slot = t & 7, y = t >> 3;
+    const int f = blockIdx.y;
+    if (y >= d.h || slot >= 6) return;
+    const double yc = (double)y + 0.5;
+    const double a1y = __dmul_rn(P.m[1], yc);
+    const double yin = __dadd_rn(yc, P.m[5]);
+    const bool yok = yin >= 0.0 && yin < (double)s.h;
+    if (!yok) return;                                       // whole row is fill: nothing was left out
+    const int yi = (int)floor(yin - 0.5);
+    const u8* row = s.p + (int64_t)f * s.fs + (int64_t)clampi(yi, 0, s.h - 1) * s.rs;
+    const double u = __dadd_rn(a1y, P.m[2]);
+    const double fu = floor(u), du = u - fu;
+    const double eps = 9.313225746154785e-10;
+    const bool row_fast = du > eps && du < 1.0 - eps && fabs(du - 0.5) > eps && fabs(fu) < 1.0e9;
+    if (!row_fast) return;                                  // the main kernel did this row pixel by pixel
+    const int iu = (int)fu;
+    // candidate groups: x0 = 4 * floor(a / 4) + 4 * (slot % 3) around the first (a = -iu - 4) and the
+    // last (a = w - 6 - iu) source columns
+    const int a = slot < 3 ? -iu - 4 : s.w - 6 - iu;
+    const int x0 = ((a >> 2) << 2) + 4 * (slot % 3);
+    if (x0 < 0 || x0 + 4 > d.w) return;                     // (ragged last group: done by the main kernel)
+    if (slot >= 3) {                                        // do not redo a group the left window already covers
+        const int al = -iu - 4, xl = ((al >> 2) << 2);
+        if (x0 >= xl && x0 <= xl + 8) return;
+    }
+    const int xi0 = x0 + iu;
+    if (xi0 >= 1 && xi0 + 7 <= s.w && x0 + 4 <= d.w) return;   // an ordinary group: the main kernel did it
+    for (int k = 0; k < 4 && x0 + k < d.w; ++k) {
+        const int xi = xi0 + k;
+        const bool ok = du < 0.5 ? (xi >= 0 && xi <= s.w - 1) : (xi >= -1 && xi <= s.w - 2);
+        if (!ok) continue;                                  // fill colour, already written
+        u8 px[C];
+        shear_exact_px(s, P, row, yok, a1y, x0 + k, px);
+        u8* dp = d.row(f, y) + (x0 + k) * C;
+        dp[0] = px[0]; dp[1] = px[1]; dp[2] = px[2];
+    }
+}
+
+template <bool PRECISE, bool DEFER>   // DEFER: unit-step rows leave their edge groups to shear_edges_kernel
 __global__ __launch_bounds__(256) void shear_bicubic_kernel(View s, View d, AffineParams P) {
     constexpr int C = 3;
     constexpr float GUARD = 4.0e-4f;
     const int lane = threadIdx.x & 63;
-    const int xg = blockIdx.x * 64 + lane;          // group of 4 output pixels
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int wv = threadIdx.x >> 6;
+    const int xg = (blockIdx.x * 4 + wv) * 64 + lane;   // group of 4 output pixels; a workgroup = 1024 pixels of one row
+    const int y = blockIdx.y;
     const int f = blockIdx.z;
     const int x0 = xg * 4;
     if (y >= d.h || x0 >= d.w) return;
@@ -1032,33 +1106,81 @@ __global__ __launch_bounds__(256) void shear_bicubic_kernel(View s, View d, Affi
     const int yi = (int)floor(yin - 0.5);
     const u8* row = sp + (int64_t)clampi(yi, 0, s.h - 1) * s.rs;
 
-    auto exact_px = [&](int x, u8 (&px)[C]) {
-        const double xc = (double)x + 0.5;
-        double xin = __dadd_rn(__dadd_rn(__dmul_rn(P.m[0], xc), a1y), P.m[2]);
-        if (!(yok && xin >= 0.0 && xin < (double)s.w)) {
-#pragma unroll
-            for (int j = 0; j < C; ++j) px[j] = P.fill[j];
-            return;
-        }
-        xin -= 0.5;
-        const double xfl = floor(xin);
-        const int xi = (int)xfl;
-        const double dx = xin - xfl;
-        int xs[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) xs[t] = clampi(xi - 1 + t, 0, s.w - 1) * C;
-#pragma unroll
-        for (int j = 0; j < C; ++j) {
-            const double v = cubic<PreciseArith>((double)row[xs[0] + j], (double)row[xs[1] + j],
-                                                 (double)row[xs[2] + j], (double)row[xs[3] + j], dx);
-            px[j] = v <= 0.0 ? (u8)0 : (v >= 255.0 ? (u8)255 : (u8)(int)v);
-        }
-    };
+    auto exact_px = [&](int x, u8 (&px)[C]) { shear_exact_px(s, P, row, yok, a1y, x, px); };
 
     u32 od[C] = {0u, 0u, 0u};
     u32 need = 0;
+    // ---- unit-step rows (m0 == 1: apply_shear).  Then xin(x) - 0.5 = x + u with u = a1*yc + a2 up
+    // to 3 * 2^-40 of rounding, so every pixel of the row has the same fraction d = frac(u) and
+    // source column x + floor(u), unless d is within 2^-30 of 0, 0.5 (the bounds test) or 1 — those
+    // rows take the per-pixel path below.  The cubic is then the fixed 4-tap filter
+    //   w1 = -d + 2d^2 - d^3,  w2 = 1 - 2d^2 + d^3,  w3 = d + d^2 - d^3,  w4 = -d^2 + d^3
+    // (libImaging's Horner form expanded; weights from fp64, rounded once), a lane's 4 pixels share
+    // 7 source pixels = one 24-byte load and 21 conversions, and |fp32 - fp64| <= 1.26 * 255 * 2^-25
+    // + 4 * 1.5e-5 = 7e-5 < GUARD_ROW.
+    constexpr float GUARD_ROW = 1.2e-4f;
+    bool done = false;
+    if (P.m[0] == 1.0) {
+        const double u = __dadd_rn(a1y, P.m[2]);
+        const double fu = floor(u), du = u - fu;
+        const double eps = 9.313225746154785e-10;      // 2^-30
+        const bool row_sure = du > eps && du < 1.0 - eps && fabs(du - 0.5) > eps;
+        const int xi0 = x0 + (int)fu;
+        const bool row_fast = row_sure && fabs(fu) < 1.0e9;
+        if (row_fast && !(yok && xi0 >= 1 && xi0 + 7 <= s.w && x0 + 4 <= d.w)) {
+            // lanes at the ends of the source row or in the fill triangles: the bounds test is
+            // integer here (d is not within 2^-30 of 0 / 0.5 / 1), outside pixels are the fill
+            // colour, the few inside ones go to the fp64 hand-back
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xi = xi0 + k;
+                const bool ok = yok && (du < 0.5 ? (xi >= 0 && xi <= s.w - 1) : (xi >= -1 && xi <= s.w - 2));
+                if (ok) {
+                    if (!DEFER || x0 + 4 > d.w) need |= 1u << k;      // (a ragged last group is never deferred)
+                } else {
+#pragma unroll
+                    for (int j = 0; j < C; ++j) {
+                        const int q = (k * C + j) >> 2, sh = ((k * C + j) & 3) * 8;
+                        od[q] |= (u32)P.fill[j] << sh;
+                    }
+                }
+            }
+            done = true;
+        }
+        if (row_fast && !done) {
+            const double d2 = du * du, d3 = d2 * du;
+            const float w1 = (float)(-du + 2.0 * d2 - d3), w2 = (float)(1.0 - 2.0 * d2 + d3);
+            const float w3 = (float)(du + d2 - d3), w4 = (float)(-d2 + d3);
+            const u8* tp = row + (xi0 - 1) * C;                               // source pixels xi0-1 .. xi0+5 (+3 spare bytes)
+            const u32x4_ua q4 = *(const u32x4_ua*)tp;
+            const u32x2_sh q2 = *(const u32x2_sh*)(tp + 16);
+            const u32 w[6] = {q4.x, q4.y, q4.z, q4.w, q2.x, q2.y};
+            float T[7][C];
+#pragma unroll
+            for (int pp = 0; pp < 7; ++pp)
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    const int b = pp * C + j;
+                    T[pp][j] = (float)((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float dist = 0.0f;
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    const float v = fmaf(w4, T[k + 3][j], fmaf(w3, T[k + 2][j], fmaf(w2, T[k + 1][j], w1 * T[k][j])));
+                    const float fl = floorf(v);
+                    od[(k * C + j) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(fl, (k * C + j) & 3, od[(k * C + j) >> 2]);
+                    if (PRECISE) dist = fmaxf(dist, fabsf((v - fl) - 0.5f));
+                }
+                need |= (PRECISE && dist > 0.5f - GUARD_ROW) ? 1u << k : 0u;
+            }
+            done = true;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        if (done) break;
         const int x = x0 + k;
         const double xc = (double)x + 0.5;
         const double xin = __dadd_rn(__dadd_rn(__dmul_rn(P.m[0], xc), a1y), P.m[2]);
@@ -1107,6 +1229,16 @@ __global__ __launch_bounds__(256) void shear_bicubic_kernel(View s, View d, Affi
     }
     u8* dp = d.row(f, y) + x0 * C;
     const int npx = min(4, d.w - x0);
+    // a full wave (256 pixels of one row, 768 contiguous bytes) goes through the LDS transpose:
+    // 48 dense 16-byte stores instead of three dword stores at a 12-byte lane stride
+    const int xw0 = (blockIdx.x * 4 + wv) * 256;
+    const bool dense = xw0 + 256 <= d.w &&
+                       ((((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs | (uintptr_t)(xw0 * C)) & 15) == 0;
+    if (dense) {
+        __shared__ __attribute__((aligned(16))) u32 stage[4][64 * C + 2 + 4];
+        staged_store<C, 64>(stage[threadIdx.x >> 6], od, lane, d.row(f, y) + xw0 * C);
+        return;
+    }
     if (npx == 4 && ((((uintptr_t)dp) & 3) == 0)) {
 #pragma unroll
         for (int q = 0; q < C; ++q) ((u32*)dp)[q] = od[q];
@@ -1352,9 +1484,17 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
         static const bool no_shear = getenv("IMGXF_AFFINE_NO_SHEAR_FAST") != nullptr;
         const bool honly = m[3] == 0.0 && m[4] == 1.0 && m[5] == floor(m[5]) && fabs(m[5]) < 1.0e9;
         if (filter == IMGXF_FILTER_BICUBIC && honly && src->c == 3 && !dbg.p && !no_shear && src->w >= 4) {
-            dim3 block(256), grid((unsigned)((d.w + 255) / 256), (unsigned)((d.h + 3) / 4), (unsigned)d.n);
-            if (pr) hipLaunchKernelGGL((shear_bicubic_kernel<true>), grid, block, 0, st, s, d, P);
-            else hipLaunchKernelGGL((shear_bicubic_kernel<false>), grid, block, 0, st, s, d, P);
+            dim3 block(256), grid((unsigned)((d.w + 1023) / 1024), (unsigned)d.h, (unsigned)d.n);
+            if (m[0] == 1.0) {
+                // unit-step rows (apply_shear): main pass + a tiny pass over the row-end groups
+                if (pr) hipLaunchKernelGGL((shear_bicubic_kernel<true, true>), grid, block, 0, st, s, d, P);
+                else hipLaunchKernelGGL((shear_bicubic_kernel<false, true>), grid, block, 0, st, s, d, P);
+                IMGXF_CHECK(launch_status());
+                hipLaunchKernelGGL(shear_edges_kernel, dim3((unsigned)((d.h * 8 + 255) / 256), (unsigned)d.n), dim3(256), 0, st, s, d, P);
+                return launch_status();
+            }
+            if (pr) hipLaunchKernelGGL((shear_bicubic_kernel<true, false>), grid, block, 0, st, s, d, P);
+            else hipLaunchKernelGGL((shear_bicubic_kernel<false, false>), grid, block, 0, st, s, d, P);
             return launch_status();
         }
     }

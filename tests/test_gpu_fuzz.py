@@ -166,3 +166,25 @@ def test_fused_background_stages(device, hw):
     mask = dev(((rng.random((2, h, w, 1)) < 0.3) * int(rng.integers(1, 256))).astype(np.uint8), device)
     want = ops.composite(t, ops.new(t, h, w, (10, 200, 30)), mask)
     assert torch.equal(ops.composite_const(t, (10, 200, 30), mask), want)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_unit_step_bicubic_rows(device, seed):
+    """Horizontal-only bicubic with m0 == 1 (the row-constant fast path of the shear kernel plus its
+    row-end pass): random shear / shift incl. negative ones, integer row offsets, outputs narrower
+    and wider than the source, tiny and 16-byte-aligned widths, fractions near 0 / 0.5 / 1."""
+    from imagetransformations_amd import ops
+    rng = np.random.default_rng(5000 + seed)
+    h = int(rng.integers(3, 90))
+    w = int(rng.choice([4, 5, 7, 9, 16, 33, 64, 257, 300, 1040]))
+    a = rnd_image(rng, h, w)
+    t = dev(a, device)
+    for _ in range(6):
+        a1 = float(rng.choice([0.0, 0.3, -0.3, 0.5, 1.0, 0.123456789, -0.77]))
+        a2 = float(rng.choice([0.0, -3.0, 2.5, -0.5, 1e-12, 0.4999999999, float(rng.uniform(-w, w))]))
+        m5 = float(rng.integers(-2, 3))
+        ow = int(rng.choice([w, w + 13, max(1, w - 3), 2 * w + 1, 3]))
+        m = (1.0, a1, a2, 0.0, 1.0, m5)
+        want = O.affine_bicubic(a, (ow, h), m, fill=(255, 255, 255))
+        got = host(ops.affine(t, m, (ow, h), ops.BICUBIC, (255, 255, 255), precise=True))
+        assert np.array_equal(got, want), (h, w, m, ow, int((got != want).sum()))
