@@ -204,6 +204,24 @@ def flip(t: torch.Tensor, top_bottom: bool = False) -> torch.Tensor:
     return out
 
 
+def perspective(t: torch.Tensor, coeffs) -> torch.Tensor:
+    """torchvision F.perspective(float tensor, BILINEAR, fill=0) between ToTensor and ToPILImage
+    (fall_2025/transformations_code:54-66) for given coefficients: eight floats shared by all
+    frames, or one row of eight per frame of a [N,H,W,C] batch."""
+    t = _check_u8(t)
+    rows = [list(map(float, r)) for r in coeffs] if hasattr(coeffs[0], "__len__") else None
+    flat = [v for r in rows for v in r] if rows is not None else list(map(float, coeffs))
+    nfr = t.shape[0] if t.dim() == 4 else 1
+    if rows is not None and (t.dim() != 4 or len(rows) != nfr):
+        raise ValueError("per-frame coefficients need a [N,H,W,C] batch with one row of 8 per frame")
+    if len(flat) != 8 * (len(rows) if rows is not None else 1):
+        raise ValueError("perspective coefficients come in rows of eight")
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    F.call("imgxf_perspective_bilinear_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(flat),
+           1 if rows is not None else 0, _stream())
+    return out
+
+
 def rot90(t: torch.Tensor, quarter_turns_ccw: int) -> torch.Tensor:
     t = _check_u8(t)
     h, w, _ = _hwc(t)

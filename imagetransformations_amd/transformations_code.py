@@ -2,11 +2,17 @@
 (/root/reference/fall_2025/transformations_code:39-52) on the HIP kernels, same names and
 argument meaning.  Its `apply_*` functions are the same bodies as `transformation.py`'s and are
 re-exported from there.  `apply_perspective_warp` (:54-66) wraps torchvision's
-RandomPerspective, which is not installed here, so its sampling cannot be pinned; it is not
-provided (AttributeError) rather than approximated."""
+RandomPerspective on a float tensor; torchvision is not installed, so the host side restates
+its parameter draws and coefficient solve on torch's own RNG / lstsq (same generator stream,
+same values) and the kernel restates `_perspective_grid` + `grid_sample`, checked bit-for-bit
+against those torch CPU primitives (tests/test_oracle_vs_libs.py)."""
 from __future__ import annotations
 
+import os
+import random
+
 import numpy as np
+import torch
 from PIL import Image
 
 from . import ops
@@ -34,3 +40,100 @@ def rand_crop(img: Image.Image) -> Image.Image:
 def apply_random_zoom(img: Image.Image, scale_factor: float) -> Image.Image:
     """Zoom transformation (1.0 to 1.1 range) = apply_scale (:50-52)."""
     return apply_scale(img, scale_factor)
+
+
+def _perspective_endpoints(width: int, height: int, distortion_scale: float):
+    """RandomPerspective.get_params: eight torch.randint draws from torch's global CPU generator,
+    in torchvision's order (top-left x, y; top-right; bottom-right; bottom-left)."""
+    def randint(lo, hi):
+        return int(torch.randint(lo, hi, size=(1,)).item())
+    half_height, half_width = height // 2, width // 2
+    dw, dh = int(distortion_scale * half_width), int(distortion_scale * half_height)
+    topleft = [randint(0, dw + 1), randint(0, dh + 1)]
+    topright = [randint(width - dw - 1, width), randint(0, dh + 1)]
+    botright = [randint(width - dw - 1, width), randint(height - dh - 1, height)]
+    botleft = [randint(0, dw + 1), randint(height - dh - 1, height)]
+    startpoints = [[0, 0], [width - 1, 0], [width - 1, height - 1], [0, height - 1]]
+    return startpoints, [topleft, topright, botright, botleft]
+
+
+def _perspective_coeffs(startpoints, endpoints):
+    """torchvision F._get_perspective_coeffs: fp64 least squares (gels), cast to fp32."""
+    a = torch.zeros(2 * len(startpoints), 8, dtype=torch.float64)
+    for i, (p1, p2) in enumerate(zip(endpoints, startpoints)):
+        a[2 * i, :] = torch.tensor([p1[0], p1[1], 1, 0, 0, 0, -p2[0] * p1[0], -p2[0] * p1[1]], dtype=torch.float64)
+        a[2 * i + 1, :] = torch.tensor([0, 0, 0, p1[0], p1[1], 1, -p2[1] * p1[0], -p2[1] * p1[1]], dtype=torch.float64)
+    b = torch.tensor(startpoints, dtype=torch.float64).view(8)
+    return torch.linalg.lstsq(a, b, driver="gels").solution.to(torch.float32).tolist()
+
+
+def draw_perspective_coeffs(width: int, height: int, distortion_scale: float):
+    """The random part of RandomPerspective(distortion_scale, p=1.0).forward on torch's global
+    generator: the `torch.rand(1) < p` draw first (always true for p = 1), then get_params."""
+    torch.rand(1)
+    return _perspective_coeffs(*_perspective_endpoints(width, height, distortion_scale))
+
+
+def apply_perspective_warp(img: Image.Image, distortion_scale: float = 0.2) -> Image.Image:
+    """Symmetric perspective warp (:54-66): ToTensor -> RandomPerspective(distortion_scale,
+    p=1.0) -> ToPILImage.  Seed with torch.manual_seed, as for the reference."""
+    w, h = img.size
+    coeffs = draw_perspective_coeffs(w, h, distortion_scale)
+    return _download(ops.perspective(_upload(img), coeffs))
+
+
+output_dir = None       # the reference hard-codes a directory (:16); None = do not save
+
+TRANSFORMATIONS_2D = {
+    'scale': {'min': 0.9, 'max': 1.4, 'step': 0.1},
+    'rotation': {'min': -22.5, 'max': 22.5, 'step': 2.5},
+    'lighten_darken': {'min': -0.05, 'max': 0.05, 'step': 0.01},
+    'gaussian_noise': {'min': 0.0, 'max': 0.1, 'step': 0.01},
+    'translation': {'min': -50, 'max': 50, 'step': 5},
+    'contrast': {'min': 0, 'max': 1, 'step': 0.1},
+    'blur': {'min': 0, 'max': 5, 'step': 0.5},
+    'shear': {'min': 0, 'max': 1, 'step': 0.1},
+    'vert_flip': {'apply': True},
+    'rand_crop': {'apply': True},
+    'zoom': {'min': 1.0, 'max': 1.1, 'step': 0.01},
+    'perspective_warp': {'min': 0.0, 'max': 0.2, 'step': 0.05},
+}
+
+_DISPATCH = {
+    'scale': apply_scale, 'rotation': apply_rotation, 'lighten_darken': apply_brightness,
+    'gaussian_noise': apply_gaussian_noise, 'contrast': apply_contrast, 'shear': apply_shear,
+    'blur': apply_blur, 'zoom': apply_random_zoom, 'perspective_warp': apply_perspective_warp,
+}
+
+
+def apply_all_transformations(images):
+    """The twelve-transformation driver of the later variant (:68-155): images = [(PIL image,
+    name)]; per image and per type one `random.choice` over the value grid (two for the
+    translation, none for the flip and the crop), file names `{name}_{type}_{value}_corrupted.jpg`."""
+    transformed_images = []
+    total_transforms = 0
+    for i, (img, name) in enumerate(images):
+        ext = '.jpg'
+        for transform_type, params in TRANSFORMATIONS_2D.items():
+            if transform_type in ('vert_flip', 'rand_crop'):
+                new_filename = f"{name}_{transform_type}_corrupted{ext}"
+                transformed_img = vert_flip(img) if transform_type == 'vert_flip' else rand_crop(img)
+            else:
+                num_steps = int((params['max'] - params['min']) / params['step']) + 1
+                possible_values = [params['min'] + j * params['step'] for j in range(num_steps)]
+                if transform_type == 'translation':
+                    tx = random.choice(possible_values)
+                    ty = random.choice(possible_values)
+                    new_filename = f"{name}_{transform_type}_{tx}_{ty}_corrupted{ext}"
+                    transformed_img = apply_translation(img, tx, ty)
+                else:
+                    transform_value = random.choice(possible_values)
+                    new_filename = f"{name}_{transform_type}_{transform_value}_corrupted{ext}"
+                    transformed_img = _DISPATCH[transform_type](img, transform_value)
+            if output_dir is not None:
+                transformed_img.save(os.path.join(output_dir, new_filename))
+            transformed_images.append(transformed_img)
+            total_transforms += 1
+        if (i + 1) % 1000 == 0:
+            print(f"Processed {i + 1}/{len(images)} original images, created {total_transforms} transformed images")
+    return transformed_images

@@ -242,6 +242,17 @@ int imgxf_rot90_u8(const imgxf_view* src, const imgxf_view* dst, int quarter_tur
  * FLIP_TOP_BOTTOM (mode 1).  Same geometry in and out. */
 int imgxf_flip_u8(const imgxf_view* src, const imgxf_view* dst, int mode, void* stream);
 
+/* ---- perspective warp  fall_2025/transformations_code:54-66 -----------------------------*/
+/* torchvision RandomPerspective on a float tensor for given coefficients: ToTensor (u8/255),
+ * _perspective_grid + grid_sample(bilinear, padding zeros, align_corners=False) of the image and
+ * a ones channel, img*mask + (1-mask)*0, ToPILImage (mul(255).byte()), all in fp32 in the
+ * evaluation order of the torch CPU build.  coeffs: HOST float[8] (per_frame = 0, shared by
+ * all frames) or float[n][8] (per_frame = 1), as returned by torchvision's
+ * _get_perspective_coeffs (output pixel -> source).  src and dst have the same n, h, w, c
+ * (c in {1,3,4}) and must not alias. */
+int imgxf_perspective_bilinear_u8(const imgxf_view* src, const imgxf_view* dst,
+                                  const float* coeffs, int per_frame, void* stream);
+
 /* ---- mask stage of apply_background_change  transformation.py:340-341 -----------------*/
 /* 256-bin histogram per frame of a c==1 view into hist[n][256] (uint32, device, zeroed by the call). */
 int imgxf_histogram_u8(const imgxf_view* src, uint32_t* hist, void* stream);

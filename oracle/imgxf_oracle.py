@@ -985,6 +985,118 @@ def rand_crop(img, x, y):
     return resize(np.ascontiguousarray(a[y:y + cs, x:x + cs]), (32, 32), RESAMPLE_BICUBIC)
 
 
+def _fma32(a, b, c):
+    """Exact fp32 fused multiply-add.  The product of two fp32 values is exact in fp64; the sum
+    with c is rounded to odd in fp64 (TwoSum gives the rounding error, an inexact even result
+    moves to its odd neighbour on the error's side), after which the rounding to fp32 is the
+    single correct one (53 >= 2*24 + 2)."""
+    p = np.asarray(a, np.float64) * np.asarray(b, np.float64)
+    c = np.asarray(c, np.float64)
+    p, c = np.broadcast_arrays(p, c)
+    s = p + c
+    bb = s - p
+    e = (p - (s - bb)) + (c - bb)
+    even = (s.view(np.int64) & 1) == 0
+    nudge = (e != 0) & even & np.isfinite(s)
+    s = np.where(nudge, np.nextafter(s, np.where(e > 0, np.inf, -np.inf)), s)
+    return s.astype(np.float32)
+
+
+def perspective_endpoints(width, height, distortion_scale, randint):
+    """torchvision.transforms.RandomPerspective.get_params (torchvision/transforms/transforms.py),
+    the draw order behind fall_2025/transformations_code:61-65: `randint(lo, hi)` stands for
+    int(torch.randint(lo, hi, size=(1,)).item()), called eight times in this order."""
+    hh, hw = height // 2, width // 2
+    dw, dh = int(distortion_scale * hw), int(distortion_scale * hh)
+    topleft = [randint(0, dw + 1), randint(0, dh + 1)]
+    topright = [randint(width - dw - 1, width), randint(0, dh + 1)]
+    botright = [randint(width - dw - 1, width), randint(height - dh - 1, height)]
+    botleft = [randint(0, dw + 1), randint(height - dh - 1, height)]
+    start = [[0, 0], [width - 1, 0], [width - 1, height - 1], [0, height - 1]]
+    return start, [topleft, topright, botright, botleft]
+
+
+def perspective_coeffs(startpoints, endpoints):
+    """torchvision.transforms.functional._get_perspective_coeffs: the eight coefficients that map
+    an OUTPUT pixel to its source, least squares in fp64 (here an 8x8 solve), cast to fp32."""
+    a = np.zeros((8, 8), np.float64)
+    for i, (p1, p2) in enumerate(zip(endpoints, startpoints)):
+        a[2 * i] = [p1[0], p1[1], 1, 0, 0, 0, -p2[0] * p1[0], -p2[0] * p1[1]]
+        a[2 * i + 1] = [0, 0, 0, p1[0], p1[1], 1, -p2[1] * p1[0], -p2[1] * p1[1]]
+    b = np.asarray(startpoints, np.float64).reshape(8)
+    return np.linalg.solve(a, b).astype(np.float32)
+
+
+def perspective_grid(coeffs, ow, oh):
+    """torchvision.transforms._functional_tensor._perspective_grid in fp32: normalised sampling
+    coordinates for pixel centres (x+0.5, y+0.5).  The two `bmm`s reduce over three terms; the
+    accumulation order fma(1, c, fma(y, b, x*a)) is the one the installed torch 2.10 CPU build
+    produces bit-for-bit (tests/test_oracle_vs_libs.py)."""
+    f32 = np.float32
+    c = [f32(v) for v in coeffs]
+    sx, sy = f32(0.5 * ow), f32(0.5 * oh)
+    t = [c[0] / sx, c[1] / sx, c[2] / sx, c[3] / sy, c[4] / sy, c[5] / sy]
+    x = (np.arange(ow, dtype=f32) + f32(0.5))[None, :]
+    y = (np.arange(oh, dtype=f32) + f32(0.5))[:, None]
+
+    def dot3(a, b, cc):
+        return _fma32(y, b, x * a) + cc
+
+    den = dot3(c[6], c[7], f32(1))
+    return dot3(t[0], t[1], t[2]) / den - f32(1), dot3(t[3], t[4], t[5]) / den - f32(1)
+
+
+def grid_sample_bilinear_zeros(t, gx, gy):
+    """torch.nn.functional.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False)
+    on an HWC fp32 image (ATen/native/cpu/GridSamplerKernel.cpp), with the contraction pattern of
+    the installed CPU build: unnormalise = fma(g+1, size, -1)/2; weights from the distances to the
+    four sides; the four taps accumulated nw, ne, sw, se as one multiply then three fmas.
+    Returns (sampled image, sampled all-ones mask)."""
+    f32 = np.float32
+    h, w = t.shape[:2]
+    one = f32(1)
+    ix = _fma32(gx + one, f32(w), f32(-1)) / f32(2)
+    iy = _fma32(gy + one, f32(h), f32(-1)) / f32(2)
+    x0, y0 = np.floor(ix), np.floor(iy)
+    ww = ix - x0
+    we = one - ww
+    wn = iy - y0
+    ws = one - wn
+    wts = [ws * we, ws * ww, wn * we, wn * ww]
+    xi, yi = x0.astype(np.int64), y0.astype(np.int64)
+    acc = msk = None
+    for (dx, dy), wt in zip(((0, 0), (1, 0), (0, 1), (1, 1)), wts):
+        xx, yy = xi + dx, yi + dy
+        ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+        v = np.where(ok[..., None], t[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)], f32(0))
+        m = np.where(ok, one, f32(0))
+        if acc is None:
+            acc, msk = v * wt[..., None], m * wt
+        else:
+            acc = _fma32(v, np.broadcast_to(wt[..., None], v.shape), acc)
+            msk = _fma32(m, wt, msk)
+    return acc, msk
+
+
+def perspective_warp(img, coeffs):
+    """fall_2025/transformations_code:54-66 for drawn coefficients: ToTensor (u8/255 in fp32),
+    F.perspective(BILINEAR, fill=[0,0,0]) = grid_sample of the image plus a ones channel, then
+    img*mask + (1-mask)*fill (torchvision _apply_grid_transform), ToPILImage = mul(255).byte()
+    (truncation)."""
+    a = np.asarray(img, np.uint8)
+    if a.ndim == 2:
+        a = a[..., None]
+    h, w = a.shape[:2]
+    f32 = np.float32
+    t = a.astype(f32) / f32(255)
+    gx, gy = perspective_grid(coeffs, w, h)
+    s, m = grid_sample_bilinear_zeros(t, gx, gy)
+    m = m[..., None]
+    out = (s * m + (f32(1) - m) * f32(0)) * f32(255)
+    out = np.minimum(out, f32(255)).astype(np.uint8)
+    return out if np.asarray(img).ndim == 3 else out[..., 0]
+
+
 def posterize_lut(bits):
     """ImageOps.posterize (PIL/ImageOps.py): lut[i] = i & ~(2**(8-bits)-1)."""
     mask = ~(2 ** (8 - int(bits)) - 1)

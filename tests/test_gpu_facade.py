@@ -382,8 +382,6 @@ def test_transformations_code_extras(device):
                 assert np.array_equal(got[0], np.asarray(img.resize(size, flt))), (hw, size, flt)
                 assert np.array_equal(got[1], np.asarray(Image.fromarray(a[::-1].copy()).resize(size, flt)))
         assert np.array_equal(ops.flip(t, top_bottom=True).cpu().numpy()[0], a[::-1])
-    with pytest.raises(AttributeError):
-        T.apply_perspective_warp
 
 
 def test_batched_driver_equals_per_image_driver(device):

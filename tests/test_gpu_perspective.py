@@ -1,0 +1,152 @@
+"""GPU: apply_perspective_warp (fall_2025/transformations_code:54-66) and its kernel through the
+C-ABI against the oracle, which tests/test_oracle_vs_libs.py pins bit-for-bit on torch's CPU
+grid_sample.  fp32 path: the kernel repeats the CPU build's operation order, so the comparison
+is exact; the tolerance the contract would allow (1 LSB from the final truncation) is not used."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth
+from oracle import imgxf_oracle as O
+
+pytestmark = pytest.mark.gpu
+Image = pytest.importorskip("PIL.Image")
+
+
+def _coeffs(w, h, ds, seed):
+    g = torch.Generator().manual_seed(seed)
+    st, en = O.perspective_endpoints(w, h, ds, lambda lo, hi: int(torch.randint(lo, hi, size=(1,), generator=g).item()))
+    return [float(v) for v in O.perspective_coeffs(st, en)]
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (37, 61), (334, 500), (200, 3), (5, 301), (1, 1), (129, 257)])
+def test_kernel_matches_oracle(device, hw):
+    from imagetransformations_amd import ops
+    h, w = hw
+    for ch in (3, 1, 4):
+        a = synth(7 + ch, h, w, ch)
+        for k, ds in enumerate((0.0, 0.05, 0.2, 0.6, 1.0)):
+            c = _coeffs(w, h, ds, 10 * k + ch) if min(h, w) > 1 else [1.0 + ds, 0.1, -0.3, 0.0, 1.0, 0.2 * ds, 0.01, 0.0]
+            got = ops.perspective(torch.from_numpy(a).to(device), c).cpu().numpy()
+            assert np.array_equal(got, O.perspective_warp(a, c)), (hw, ch, ds)
+
+
+def test_per_frame_coefficients_and_strided_batches(device):
+    from imagetransformations_amd import ops
+    h, w, n = 70, 90, 53                      # more frames than one launch carries coefficients for
+    frames = np.stack([synth(200 + i, h, w) for i in range(n)])
+    cs = [_coeffs(w, h, (0.1, 0.2, 0.4)[i % 3], i) for i in range(n)]
+    t = torch.from_numpy(frames).to(device)
+    got = ops.perspective(t, cs).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], O.perspective_warp(frames[i], cs[i])), i
+    shared = ops.perspective(t, cs[1]).cpu().numpy()
+    for i in (0, 17, 52):
+        assert np.array_equal(shared[i], O.perspective_warp(frames[i], cs[1]))
+    wide = torch.zeros((n, h, w + 11, 3), dtype=torch.uint8, device=device)
+    wide[:, :, 4:4 + w] = t
+    view = wide[::2, :, 4:4 + w]              # frame stride 2 images, row stride wider than a row
+    got = ops.perspective(view, cs[2]).cpu().numpy()
+    for j, i in enumerate(range(0, n, 2)):
+        assert np.array_equal(got[j], O.perspective_warp(frames[i], cs[2])), i
+
+
+def test_extreme_coefficients(device):
+    """Maps the staged-box argument does not cover (denominator changing sign inside the image,
+    strong minification, everything outside) take the global-memory path; same bytes."""
+    from imagetransformations_amd import ops
+    h, w = 96, 160
+    a = synth(5, h, w)
+    t = torch.from_numpy(a).to(device)
+    cases = [
+        [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, -0.0125, 0.0],          # denominator zero at x = 80
+        [1.0, 0.2, 3.0, -0.1, 1.0, 1.0, 0.004, -0.02],
+        [9.0, 0.0, -300.0, 0.0, 7.0, -200.0, 0.0, 0.0],        # 9x minification: boxes too large for LDS
+        [1.0, 0.0, 5000.0, 0.0, 1.0, 0.0, 0.0, 0.0],           # entirely outside
+        [0.0, 0.0, 10.0, 0.0, 0.0, 20.0, 0.0, 0.0],            # constant source position
+        [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0],              # identity
+        [-1.0, 0.0, 159.0, 0.0, -1.0, 95.0, 0.0, 0.0],         # point reflection
+        [1e-3, 0.0, 0.5, 0.0, 1e-3, 0.5, 0.0, 0.0],
+    ]
+    for c in cases:
+        got = ops.perspective(t, c).cpu().numpy()
+        with np.errstate(all="ignore"):
+            want = O.perspective_warp(a, c)
+        assert np.array_equal(got, want), c
+
+
+def test_full_hd_frame(device):
+    from imagetransformations_amd import ops
+    h, w = 1080, 1920
+    a = synth(77, h, w)
+    c = _coeffs(w, h, 0.2, 3)
+    got = ops.perspective(torch.from_numpy(a).to(device), c).cpu().numpy()
+    assert np.array_equal(got, O.perspective_warp(a, c))
+
+
+def test_facade_draws_and_pixels(device):
+    """apply_perspective_warp(img, v): same torch generator stream as RandomPerspective(v, p=1)."""
+    from imagetransformations_amd import transformations_code as TC
+    for seed, hw in enumerate([(32, 32), (61, 37), (334, 500)]):
+        a = synth(seed, *hw)
+        img = Image.fromarray(a)
+        for ds in (0.0, 0.05, 0.1, 0.15000000000000002, 0.2):
+            torch.manual_seed(seed)
+            got = np.asarray(TC.apply_perspective_warp(img, ds))
+            torch.manual_seed(seed)
+            torch.rand(1)
+            st, en = O.perspective_endpoints(hw[1], hw[0], ds, lambda lo, hi: int(torch.randint(lo, hi, size=(1,)).item()))
+            c = [float(v) for v in O.perspective_coeffs(st, en)]
+            want = O.perspective_warp(a, c)
+            # the host solves with torch.linalg.lstsq (as torchvision does), the oracle with an 8x8
+            # solve: the fp32 coefficients may differ in the last bit, which can move a byte by 1
+            diff = np.abs(got.astype(int) - want.astype(int))
+            assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (hw, ds, diff.max(), (diff != 0).mean())
+    grey = Image.fromarray(synth(9, 40, 50)[..., 0].copy())
+    torch.manual_seed(1)
+    out = TC.apply_perspective_warp(grey, 0.2)
+    assert out.mode == "L" and out.size == grey.size
+
+
+def test_twelve_transformation_driver(device):
+    """fall_2025/transformations_code:68-155: twelve outputs per image, the reference's names."""
+    from imagetransformations_amd import transformations_code as TC
+    imgs = [(Image.fromarray(synth(40 + i, 32, 32)), f"cifar10_test_{i}_label_{i % 10}") for i in range(3)]
+    random.seed(4); np.random.seed(4); torch.manual_seed(4)
+    out = TC.apply_all_transformations(imgs)
+    assert len(out) == 12 * len(imgs)
+    keys = list(TC.TRANSFORMATIONS_2D)
+    assert all(o.mode == "RGB" and (o.size == (32, 32) or keys[j % 12] == 'shear') for j, o in enumerate(out))
+    # replay the draws: the flip and every deterministic body can be checked per pixel
+    random.seed(4)
+    for i, (img, name) in enumerate(imgs):
+        a = np.asarray(img)
+        vals = {}
+        for t, prm in TC.TRANSFORMATIONS_2D.items():
+            if 'apply' in prm:
+                continue
+            steps = int((prm['max'] - prm['min']) / prm['step']) + 1
+            grid = [prm['min'] + j * prm['step'] for j in range(steps)]
+            vals[t] = (random.choice(grid), random.choice(grid)) if t == 'translation' else random.choice(grid)
+        res = dict(zip(keys, out[12 * i:12 * i + 12]))
+        assert np.array_equal(np.asarray(res['scale']), O.apply_scale(a, vals['scale']))
+        assert np.array_equal(np.asarray(res['rotation']), O.apply_rotation(a, vals['rotation']))
+        assert np.array_equal(np.asarray(res['shear']), O.apply_shear(a, vals['shear']))
+        assert np.array_equal(np.asarray(res['zoom']), O.apply_scale(a, vals['zoom']))
+        assert np.array_equal(np.asarray(res['vert_flip']), a[:, ::-1])
+        assert np.array_equal(np.asarray(res['translation']), O.apply_translation(a, *vals['translation']))
+
+
+def test_error_paths(device):
+    from imagetransformations_amd import ops
+    t = torch.zeros((2, 8, 8, 3), dtype=torch.uint8, device=device)
+    ident = [1.0, 0, 0, 0, 1.0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        ops.perspective(t, ident[:7])
+    with pytest.raises(ValueError):
+        ops.perspective(t, [ident])                       # one row for two frames
+    with pytest.raises(Exception):
+        ops.perspective(t, [float("nan")] + ident[1:])
+    assert ops.perspective(t[:0], ident).shape == (0, 8, 8, 3)

@@ -196,3 +196,46 @@ def test_cv_colour_space_restatement_properties():
     assert (np.diff(e.ravel()[order].astype(int)) >= 0).all()
     assert e[y == y.min()].max() == 0 and e.max() == 255
     assert np.array_equal(O.equalize_hist_cv(np.full((5, 5), 9, np.uint8)), np.full((5, 5), 9, np.uint8))
+
+
+def _persp_cases():
+    import torch
+    rng = np.random.default_rng(11)
+    for trial in range(24):
+        w, h = int(rng.integers(8, 160)), int(rng.integers(8, 160))
+        g = torch.Generator().manual_seed(trial)
+        ds = (0.0, 0.05, 0.1, 0.2, 0.5, 0.9)[trial % 6]
+        st, en = O.perspective_endpoints(w, h, ds, lambda lo, hi: int(torch.randint(lo, hi, size=(1,), generator=g).item()))
+        yield trial, w, h, st, en
+
+
+def test_perspective_warp_vs_torch_primitives():
+    """fall_2025/transformations_code:54-66: the oracle's fp32 restatement of torchvision's
+    _perspective_grid + grid_sample + mask blend + mul(255).byte() equals, bit for bit, the same
+    pipeline run on the installed torch's CPU primitives (tests/tv_perspective_ref.py)."""
+    pytest.importorskip("torch")
+    import tv_perspective_ref as TV
+    for trial, w, h, st, en in _persp_cases():
+        c = TV.coeffs(st, en)
+        c2 = O.perspective_coeffs(st, en)
+        assert np.allclose(np.asarray(c, np.float64), c2, rtol=1e-5, atol=1e-9), (st, en)
+        for ch in (3, 1, 4):
+            a = synth(100 + trial, h, w, ch) if ch != 1 else synth(100 + trial, h, w)[..., 0].copy()
+            assert np.array_equal(O.perspective_warp(a, c), TV.perspective_u8(a, c)), (trial, w, h, ch)
+
+
+def test_perspective_draws_follow_torch_generator():
+    """The host side of apply_perspective_warp consumes torch's global generator exactly as
+    RandomPerspective(p=1).forward does: one rand, then eight randints."""
+    torch = pytest.importorskip("torch")
+    import tv_perspective_ref as TV
+    from imagetransformations_amd import transformations_code as TC
+    for seed, (w, h, ds) in enumerate([(32, 32, 0.2), (500, 334, 0.15), (61, 37, 0.0), (3840, 2160, 0.2)]):
+        torch.manual_seed(seed)
+        got = TC.draw_perspective_coeffs(w, h, ds)
+        torch.manual_seed(seed)
+        torch.rand(1)
+        st, en = O.perspective_endpoints(w, h, ds, lambda lo, hi: int(torch.randint(lo, hi, size=(1,)).item()))
+        assert got == TV.coeffs(st, en)
+        for p, (lo, hi) in zip(en, [((0, 0), (w // 2, h // 2)), ((w // 2, 0), (w, h // 2)), ((w // 2, h // 2), (w, h)), ((0, h // 2), (w // 2, h))]):
+            assert lo[0] <= p[0] <= hi[0] and lo[1] <= p[1] <= hi[1]

@@ -78,3 +78,17 @@ if what in ("misc", "all"):
     m = ops.percentile_mask(ops.sobel(g), 70)
     ms = timeit(lambda: ops.dilate_cross(m, 3), 5)
     print(f"dilate_cross 3 ({Fs} frames)           {ms:8.3f} ms  {Fs*H*W/ms/1e3:10.0f} Mpix/s", flush=True)
+if what in ("persp", "misc", "all"):
+    Fs = min(F, 16)
+    sub = frames[:Fs]
+    # RandomPerspective(0.2)-like corners on a 4K frame
+    import numpy as np
+    st_ = [[0, 0], [W - 1, 0], [W - 1, H - 1], [0, H - 1]]
+    en_ = [[300, 150], [W - 200, 90], [W - 350, H - 120], [120, H - 200]]
+    a_ = np.zeros((8, 8)); b_ = np.array(st_, float).reshape(8)
+    for i_, (p1, p2) in enumerate(zip(en_, st_)):
+        a_[2 * i_] = [p1[0], p1[1], 1, 0, 0, 0, -p2[0] * p1[0], -p2[0] * p1[1]]
+        a_[2 * i_ + 1] = [0, 0, 0, p1[0], p1[1], 1, -p2[1] * p1[0], -p2[1] * p1[1]]
+    co = [float(v) for v in np.linalg.solve(a_, b_).astype(np.float32)]
+    ms = timeit(lambda: ops.perspective(sub, co), 5)
+    print(f"perspective warp ({Fs} frames)         {ms:8.3f} ms  {Fs*H*W/ms/1e3:10.0f} Mpix/s  {6*Fs*H*W/ms/1e6:8.1f} GB/s", flush=True)
