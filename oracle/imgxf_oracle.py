@@ -30,6 +30,13 @@ Pinning status (see DESIGN.md "Oracle"):
     NumPy noise expressions, the entropy feature): PINNED against Pillow / NumPy / SciPy
     in tests/test_oracle_vs_libs.py.
 
+  * torchvision-backed apply_perspective_warp (fall_2025/transformations_code:54-66):
+    torchvision is not installed; its tensor path is restated here and PINNED bit for bit on
+    the torch CPU primitives it consists of (linspace / bmm / grid_sample / eager arithmetic,
+    tests/tv_perspective_ref.py, tests/test_oracle_vs_libs.py).  torchvision's own glue
+    (get_params draw order, _get_perspective_coeffs, fill handling) is restated from its
+    published source and has no installed counterpart to check against.
+
 All image arrays are HWC (or HW) uint8, C-contiguous, RGB order — exactly what
 `np.array(pil_image)` yields at `transformation.py:204,229,273`.
 """

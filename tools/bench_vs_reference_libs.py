@@ -51,6 +51,37 @@ def ref_background():
     fg = ndimage.binary_dilation(mask, iterations=3)
     return Image.composite(img, Image.new('RGB', img.size, (10, 200, 30)), Image.fromarray((fg * 255).astype(np.uint8)))
 
+def persp_coeffs():
+    st = [[0, 0], [W - 1, 0], [W - 1, H - 1], [0, H - 1]]
+    en = [[300, 150], [W - 200, 90], [W - 350, H - 120], [120, H - 200]]     # a RandomPerspective(0.2) draw
+    m = np.zeros((8, 8)); b = np.array(st, float).reshape(8)
+    for i, (p1, p2) in enumerate(zip(en, st)):
+        m[2 * i] = [p1[0], p1[1], 1, 0, 0, 0, -p2[0] * p1[0], -p2[0] * p1[1]]
+        m[2 * i + 1] = [0, 0, 0, p1[0], p1[1], 1, -p2[1] * p1[0], -p2[1] * p1[1]]
+    return [float(v) for v in np.linalg.solve(m, b).astype(np.float32)]
+
+PC = persp_coeffs()
+
+def ref_perspective():
+    """ToTensor -> F.perspective (tensor path: grid + grid_sample + mask blend) -> ToPILImage, on the
+    torch CPU primitives torchvision is made of (torchvision itself is not installed)."""
+    import torch.nn.functional as Fn
+    t = torch.from_numpy(a).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    th1 = torch.tensor([[[PC[0], PC[1], PC[2]], [PC[3], PC[4], PC[5]]]])
+    th2 = torch.tensor([[[PC[6], PC[7], 1.0], [PC[6], PC[7], 1.0]]])
+    base = torch.empty(1, H, W, 3)
+    base[..., 0].copy_(torch.linspace(0.5, W - 0.5, steps=W))
+    base[..., 1].copy_(torch.linspace(0.5, H - 0.5, steps=H).unsqueeze_(-1))
+    base[..., 2].fill_(1)
+    g1 = base.view(1, H * W, 3).bmm(th1.transpose(1, 2) / torch.tensor([0.5 * W, 0.5 * H]))
+    g2 = base.view(1, H * W, 3).bmm(th2.transpose(1, 2))
+    grid = (g1 / g2 - 1.0).view(1, H, W, 2)
+    im = torch.cat((t.unsqueeze(0), torch.ones(1, 1, H, W)), dim=1)
+    im = Fn.grid_sample(im, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    mask = im[:, -1:].expand(1, 3, H, W)
+    im = im[:, :-1] * mask + (1.0 - mask) * torch.zeros(1, 3, 1, 1)
+    return im.squeeze(0).mul(255).byte()
+
 rows = [
     ("apply_rotation 30 (Image.rotate NEAREST)", lambda: img.rotate(-30, fillcolor=(0, 0, 0)), lambda: T._rotation_t(batch, 30.0)),
     ("rotate 30 + 1.5x BILINEAR (Image.transform)", lambda: img.transform((W, H), Image.AFFINE, ops.rotate_zoom_matrix(W, H, 30.0, 1.5), Image.BILINEAR),
@@ -60,6 +91,7 @@ rows = [
     ("apply_brightness 0.05 (ImageEnhance)", lambda: ImageEnhance.Brightness(img).enhance(1.05), lambda: ops.brightness(batch, 1.05)),
     ("apply_background_change (L, sobel, percentile, dilation, composite)", ref_background,
      lambda: ops.composite_const(batch, (10, 200, 30), ops.dilate_cross(ops.percentile_mask(ops.rgb_sobel(batch), 70), 3))),
+    (f"apply_perspective_warp 0.2 (torchvision tensor path, torch CPU {torch.get_num_threads()} thr)", ref_perspective, lambda: ops.perspective(batch, PC)),
     ("ImageOps.equalize (AugMix)", lambda: __import__("PIL.ImageOps", fromlist=["equalize"]).equalize(img), lambda: ops.equalize(batch)),
 ]
 print(f"{'transformation (library call the reference makes)':72s} {'CPU ms/frame':>12s} {'HIP ms/frame':>12s} {'ratio':>8s}")
