@@ -45,6 +45,8 @@ SIGNATURES = {
     "imgxf_device_count": [],
     "imgxf_gaussian_u8": [_VP, _VP, C.c_int, C.c_double, _VP, C.c_void_p],
     "imgxf_sepconv_u8": [_VP, _VP, _F, C.c_int, _F, C.c_int, C.c_int, _VP, C.c_void_p],
+    "imgxf_gaussian_cv_fixed_u8": [_VP, _VP, C.c_int, C.c_double, C.c_void_p],
+    "imgxf_sepconv_fixed_u8": [_VP, _VP, C.POINTER(C.c_uint16), C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_void_p],
     "imgxf_conv2d_u8": [_VP, _VP, _F, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "imgxf_sobel_u8": [_VP, _VP, C.c_int, C.c_void_p],
     "imgxf_rgb_sobel_mag_u8": [_VP, _VP, C.c_void_p],

@@ -65,10 +65,17 @@ def _hwc(t: torch.Tensor):
 
 
 # ---------------------------------------------------------------- a1 Gaussian / separable
-def gaussian_blur(t: torch.Tensor, ksize: int, sigma: float, return_f32: bool = False):
-    """cv2.GaussianBlur(img, (ksize, ksize), sigma) — transformation.py:249."""
+def gaussian_blur(t: torch.Tensor, ksize: int, sigma: float, return_f32: bool = False,
+                  fixed_point: bool = False):
+    """cv2.GaussianBlur(img, (ksize, ksize), sigma) — transformation.py:249.  fixed_point=True:
+    OpenCV's 8-bit fixed-point evaluation (restated, unpinned) instead of the float definition."""
     t = _check_u8(t)
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    if fixed_point:
+        if return_f32:
+            raise ValueError("the fixed-point path has no fp32 intermediate")
+        F.call("imgxf_gaussian_cv_fixed_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), int(ksize), float(sigma), _stream())
+        return out
     f32 = torch.empty(t.shape, dtype=torch.float32, device=t.device) if return_f32 else None
     F.call("imgxf_gaussian_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), int(ksize), float(sigma),
            F.vp(F.view_of(f32)) if return_f32 else None, _stream())
@@ -83,6 +90,18 @@ def sepconv(t: torch.Tensor, kx: Sequence[float], ky: Sequence[float], border: i
     F.call("imgxf_sepconv_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(kx), len(kx),
            F.f32_array(ky), len(ky), border, F.vp(F.view_of(f32)) if return_f32 else None, _stream())
     return (out, f32) if return_f32 else out
+
+
+def sepconv_fixed(t: torch.Tensor, kx: Sequence[int], ky: Sequence[int], border: int = REFLECT_101) -> torch.Tensor:
+    """Separable filter with 8.8 fixed-point integer taps (each axis sums to <= 256), 16.16
+    columns, (v + 2^15) >> 16 — OpenCV's uint8 evaluation order."""
+    import ctypes
+    t = _check_u8(t)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    ax = (ctypes.c_uint16 * len(kx))(*[int(v) for v in kx])
+    ay = (ctypes.c_uint16 * len(ky))(*[int(v) for v in ky])
+    F.call("imgxf_sepconv_fixed_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), ax, len(kx), ay, len(ky), border, _stream())
+    return out
 
 
 # ---------------------------------------------------------------- a5 dense correlation

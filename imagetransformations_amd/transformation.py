@@ -133,12 +133,18 @@ def _blur_ksize(blur_radius: float) -> int:
     return ksize
 
 
+BLUR_FIXED_POINT = False     # True: evaluate cv2.GaussianBlur the way OpenCV's uint8 fixed-point path does
+
+
 def apply_blur(img: Image.Image, blur_radius: float) -> Image.Image:
+    """cv2.GaussianBlur by its float definition (the contract, to 1e-5 relative).  With the
+    module switch BLUR_FIXED_POINT the 8-bit fixed-point evaluation of OpenCV >= 4 is used instead
+    (restated and unpinned, but closer to the reference's own outputs)."""
     ksize = _blur_ksize(blur_radius)
     if ksize == 0:
         return img          # the reference hands back the input object itself (:245-246)
     t = _drop_alpha(_upload(img))
-    return _download(ops.gaussian_blur(t, ksize, blur_radius))
+    return _download(ops.gaussian_blur(t, ksize, blur_radius, fixed_point=BLUR_FIXED_POINT))
 
 
 # ------------------------------------------------------------------ brightness (:261-269)
@@ -330,7 +336,7 @@ def apply_all_transformations_batched(images):
                     for _, i, k in entries:
                         results[i][k] = images[i][0]    # the input object itself (:245-246)
                     continue
-                out = ops.gaussian_blur(batch, ksize, args[0])
+                out = ops.gaussian_blur(batch, ksize, args[0], fixed_point=BLUR_FIXED_POINT)
             elif transform_type == 'gaussian_noise':
                 z = torch.from_numpy(np.stack([noise[(i, k)] for _, i, k in entries])).to(dev)
                 out = ops.add_noise(batch, z)

@@ -80,6 +80,17 @@ int imgxf_sepconv_u8(const imgxf_view* src, const imgxf_view* dst, const float* 
                      const float* ky, int nky, int border, const imgxf_view* dst_f32,
                      void* stream);
 
+/* The same filter the way OpenCV >= 4 most likely evaluates it for 8-bit images (its fixed-point
+ * path; restated, cv2 is not installed — PARITY UNPINNED): taps quantised to 8 fractional bits
+ * (getGaussianKernelFixedPoint_ED: error-diffused rounding, centre = 256 - rest), 8.8 rows,
+ * 16.16 columns, (v + 2^15) >> 16.  Not the contract path (that is the float definition above);
+ * offered because the reference's own JPEG outputs sit closer to it.
+ * sepconv_fixed: host-given 8.8 integer taps, each axis summing to <= 256. */
+int imgxf_gaussian_cv_fixed_u8(const imgxf_view* src, const imgxf_view* dst, int ksize,
+                               double sigma, void* stream);
+int imgxf_sepconv_fixed_u8(const imgxf_view* src, const imgxf_view* dst, const uint16_t* kx,
+                           int nkx, const uint16_t* ky, int nky, int border, void* stream);
+
 /* ---- a5: cv2.filter2D(img,-1,kernel)  cifar_image_transformations.py:118 ------------
  * Dense kh x kw correlation, centre anchor, fp32 accumulate, round-half-even, saturate.
  * kernel: HOST pointer, row-major kh*kw floats; kh,kw odd, <= 15. */

@@ -1,0 +1,79 @@
+"""GPU: the opt-in fixed-point Gaussian (OpenCV's uint8 evaluation order, restated — parity
+unpinned, see oracle.gaussian_blur_cv_fixed) through the C-ABI against the oracle, bit for bit,
+on every kernel family behind it (marching, 4-byte marching, LDS-tiled)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth
+from oracle import imgxf_oracle as O
+
+pytestmark = pytest.mark.gpu
+Image = pytest.importorskip("PIL.Image")
+
+SHAPES = [
+    (96, 1024, 3),     # 16-byte aligned rows > 1 KiB: marching kernel (k <= 9), 4-byte marching (k >= 11)
+    (70, 352, 3),      # aligned, short rows: 4-byte marching
+    (37, 61, 3),       # unaligned: LDS-tiled kernel
+    (64, 2048, 1),
+    (48, 512, 4),
+    (33, 35, 1),
+    (5, 7, 3),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gaussian_cv_fixed_matches_oracle(device, shape):
+    from imagetransformations_amd import ops
+    h, w, c = shape
+    a = synth(h * 7 + w, h, w, c)
+    t = torch.from_numpy(a).to(device)
+    for ksize, sigma in ((3, 0.5), (5, 5 / 6), (7, 1.0), (9, 1.5), (13, 2.0), (19, 3.0), (31, 5.0), (5, 0.0), (1, 0.3)):
+        if ksize // 2 + 1 > min(h, w):
+            continue
+        sg = sigma if sigma > 0 else 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+        got = ops.gaussian_blur(t, ksize, sigma, fixed_point=True).cpu().numpy()
+        assert np.array_equal(got, O.gaussian_blur_cv_fixed(a, ksize, sg)), (shape, ksize, sigma)
+
+
+def test_fixed_taps_entry_point(device):
+    """imgxf_sepconv_fixed_u8 with the oracle's integer kernel == the Gaussian entry point; an
+    asymmetric kernel goes through the tile kernel; sums above 256 are refused."""
+    from imagetransformations_amd import ops
+    a = synth(3, 80, 1024)
+    t = torch.from_numpy(a).to(device)
+    for ksize, sigma in ((5, 5 / 6), (11, 2.0)):
+        k = [int(v) for v in O.gaussian_kernel_cv_fixed(ksize, sigma)]
+        assert sum(k) == 256
+        assert torch.equal(ops.sepconv_fixed(t, k, k), ops.gaussian_blur(t, ksize, sigma, fixed_point=True))
+    kx, ky = [10, 200, 46], [0, 0, 128, 100, 28]
+    got = ops.sepconv_fixed(t, kx, ky).cpu().numpy()
+    p = np.pad(a.astype(np.int64), ((2, 2), (1, 1), (0, 0)), mode="reflect")
+    hp = sum(kx[j] * p[:, j:j + a.shape[1]] for j in range(3))
+    vp = sum(ky[i] * hp[i:i + a.shape[0]] for i in range(5))
+    assert np.array_equal(got, ((vp + 32768) >> 16).astype(np.uint8))
+    with pytest.raises(Exception):
+        ops.sepconv_fixed(t, [100, 100, 100], [0, 256, 0])
+    with pytest.raises(ValueError):
+        ops.gaussian_blur(t, 5, 1.0, return_f32=True, fixed_point=True)
+
+
+def test_fixed_differs_from_float_by_small_steps_only(device):
+    from imagetransformations_amd import ops
+    a = synth(11, 128, 1024)
+    t = torch.from_numpy(a).to(device)
+    d = (ops.gaussian_blur(t, 5, 5 / 6, fixed_point=True).int() - ops.gaussian_blur(t, 5, 5 / 6).int()).abs()
+    assert int(d.max()) <= 2 and 0 < float((d > 0).float().mean()) < 0.2
+
+
+def test_facade_switch(device):
+    from imagetransformations_amd import transformation as T
+    a = synth(21, 64, 96)
+    img = Image.fromarray(a)
+    try:
+        T.BLUR_FIXED_POINT = True
+        got = np.asarray(T.apply_blur(img, 1.5))
+    finally:
+        T.BLUR_FIXED_POINT = False
+    assert np.array_equal(got, O.gaussian_blur_cv_fixed(a, O.blur_ksize(1.5), 1.5))
+    assert np.array_equal(np.asarray(T.apply_blur(img, 1.5)), O.apply_blur(a, 1.5))

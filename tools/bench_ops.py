@@ -92,3 +92,7 @@ if what in ("persp", "misc", "all"):
     co = [float(v) for v in np.linalg.solve(a_, b_).astype(np.float32)]
     ms = timeit(lambda: ops.perspective(sub, co), 5)
     print(f"perspective warp ({Fs} frames)         {ms:8.3f} ms  {Fs*H*W/ms/1e3:10.0f} Mpix/s  {6*Fs*H*W/ms/1e6:8.1f} GB/s", flush=True)
+if what in ("gaussfx", "all"):
+    for k, sg in ((5, 5 / 6), (13, 2.0)):
+        ms = timeit(lambda: _ffi.call("imgxf_gaussian_cv_fixed_u8", _ffi.vp(vs), _ffi.vp(vo), k, sg, st))
+        report(f"gaussian k={k} fixed-point (cv)", ms, 6)
