@@ -188,3 +188,35 @@ def test_unit_step_bicubic_rows(device, seed):
         want = O.affine_bicubic(a, (ow, h), m, fill=(255, 255, 255))
         got = host(ops.affine(t, m, (ow, h), ops.BICUBIC, (255, 255, 255), precise=True))
         assert np.array_equal(got, want), (h, w, m, ow, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_perspective_and_fixed_point_blur(device, seed):
+    """Random sizes / channel counts / coefficient draws through the perspective kernel (aligned and
+    unaligned staging, partial tiles, per-frame coefficients) and the fixed-point Gaussian."""
+    from imagetransformations_amd import ops
+    rng = np.random.default_rng(5000 + seed)
+    h, w = int(rng.integers(3, 260)), int(rng.integers(3, 400))
+    c = int(rng.choice([1, 3, 4]))
+    n = int(rng.integers(1, 4))
+    frames = np.stack([rnd_image(rng, h, w, c) for _ in range(n)])
+    if c == 1:
+        frames = frames[..., 0]
+    g = torch.Generator().manual_seed(seed)
+    cs = []
+    for i in range(n):
+        ds = float(rng.choice([0.0, 0.1, 0.2, 0.35, 0.7]))
+        st, en = O.perspective_endpoints(w, h, ds, lambda lo, hi: int(torch.randint(lo, hi, size=(1,), generator=g).item()))
+        cs.append([float(v) for v in O.perspective_coeffs(st, en)])
+    t = dev(frames, device) if c != 1 else dev(frames, device).unsqueeze(-1)
+    got = host(ops.perspective(t, cs))
+    for i in range(n):
+        want = O.perspective_warp(frames[i], cs[i])
+        assert np.array_equal(got[i] if c != 1 else got[i][..., 0], want), ("perspective", seed, h, w, c, i)
+    r = float(rng.choice([0.5, 5 / 6, 1.0, 2.0, 3.5]))
+    k = O.blur_ksize(r)
+    if h > k and w > k:
+        got = host(ops.gaussian_blur(t, k, r, fixed_point=True))
+        for i in range(n):
+            want = O.gaussian_blur_cv_fixed(frames[i], k, r)
+            assert np.array_equal(got[i] if c != 1 else got[i][..., 0], want), ("fixed blur", seed, h, w, c, k)
