@@ -137,3 +137,113 @@ def apply_all_transformations(images):
         if (i + 1) % 1000 == 0:
             print(f"Processed {i + 1}/{len(images)} original images, created {total_transforms} transformed images")
     return transformed_images
+
+
+def apply_all_transformations_batched(images):
+    """`apply_all_transformations` with the work grouped for the GPU: the same `random`,
+    `np.random` and `torch` draws in the same order, the same file names and the same pixels in
+    the same output order — but every image is uploaded once and all RGB images of one size that
+    drew the same (type, value) go through one batched launch (perspective warps and crops of one
+    size share a launch with per-frame coefficients / windows).  images: [(PIL image, name)]."""
+    from . import transformation as T
+    from .transformation import (_blur_ksize, _device, _rotation_t, _scale_t, _shear_t, _translation_t)
+    dev = _device()
+    # ---- draws, image by image, in the order the per-image loop makes them
+    plans, extra = [], {}
+    for i, (img, name) in enumerate(images):
+        w, h = img.size
+        plan = []
+        for transform_type, params in TRANSFORMATIONS_2D.items():
+            if transform_type == 'vert_flip':
+                plan.append((transform_type, (), f"{name}_{transform_type}_corrupted.jpg"))
+            elif transform_type == 'rand_crop':
+                cs = int(0.78 * w)
+                extra[(i, len(plan))] = (np.random.randint(0, w - cs + 1), np.random.randint(0, h - cs + 1), cs)
+                plan.append((transform_type, (), f"{name}_{transform_type}_corrupted.jpg"))
+            else:
+                num_steps = int((params['max'] - params['min']) / params['step']) + 1
+                possible_values = [params['min'] + j * params['step'] for j in range(num_steps)]
+                if transform_type == 'translation':
+                    tx, ty = random.choice(possible_values), random.choice(possible_values)
+                    plan.append((transform_type, (tx, ty), f"{name}_{transform_type}_{tx}_{ty}_corrupted.jpg"))
+                    continue
+                value = random.choice(possible_values)
+                if transform_type == 'gaussian_noise':
+                    shape = np.array(img).shape
+                    extra[(i, len(plan))] = np.random.normal(0, value * 255, shape).astype(np.float32)
+                elif transform_type == 'perspective_warp':
+                    extra[(i, len(plan))] = draw_perspective_coeffs(w, h, value)
+                plan.append((transform_type, (value,), f"{name}_{transform_type}_{value}_corrupted.jpg"))
+        plans.append(plan)
+
+    results = [[None] * len(p) for p in plans]
+    by_size = {}
+    for i, (img, _) in enumerate(images):
+        if img.mode == 'RGB':
+            by_size.setdefault(img.size, []).append(i)
+        else:                                           # rare: the per-image bodies, with the draws made above
+            for k, (transform_type, args, _) in enumerate(plans[i]):
+                t = _upload(img)
+                if transform_type == 'gaussian_noise':
+                    results[i][k] = _download(ops.add_noise(t, torch.from_numpy(extra[(i, k)]).to(dev)))
+                elif transform_type == 'perspective_warp':
+                    results[i][k] = _download(ops.perspective(t, extra[(i, k)]))
+                elif transform_type == 'rand_crop':
+                    x, y, cs = extra[(i, k)]
+                    results[i][k] = _download(ops.resize(ops.crop(t, (x, y, x + cs, y + cs)), (32, 32), ops.RESAMPLE_BICUBIC))
+                elif transform_type == 'vert_flip':
+                    results[i][k] = vert_flip(img)
+                elif transform_type == 'translation':
+                    results[i][k] = apply_translation(img, *args)
+                else:
+                    results[i][k] = _DISPATCH[transform_type](img, *args)
+
+    tensor_fns = {
+        'scale': _scale_t, 'zoom': _scale_t, 'rotation': _rotation_t, 'shear': _shear_t,
+        'lighten_darken': lambda t, b: ops.brightness(t, 1.0 + b),
+        'contrast': lambda t, a: ops.scale_abs(t, a, 0.0),
+        'translation': _translation_t,
+        'vert_flip': lambda t: ops.flip(t),
+    }
+    for size, members in by_size.items():
+        frames = torch.from_numpy(np.stack([np.array(images[i][0]) for i in members])).to(dev)
+        groups = {}
+        for row, i in enumerate(members):
+            for k, (transform_type, args, _) in enumerate(plans[i]):
+                key = (transform_type, args) if transform_type not in ('perspective_warp', 'rand_crop') else (transform_type, ())
+                groups.setdefault(key, []).append((row, i, k))
+        for (transform_type, args), entries in groups.items():
+            rows = torch.tensor([e[0] for e in entries], device=dev)
+            batch = frames.index_select(0, rows)
+            if transform_type == 'blur':
+                ksize = _blur_ksize(args[0])
+                if ksize == 0:
+                    for _, i, k in entries:
+                        results[i][k] = images[i][0]    # the input object itself, as the reference returns it
+                    continue
+                out = ops.gaussian_blur(batch, ksize, args[0], fixed_point=T.BLUR_FIXED_POINT)
+            elif transform_type == 'gaussian_noise':
+                z = torch.from_numpy(np.stack([extra[(i, k)] for _, i, k in entries])).to(dev)
+                out = ops.add_noise(batch, z)
+            elif transform_type == 'perspective_warp':
+                out = ops.perspective(batch, [extra[(i, k)] for _, i, k in entries])
+            elif transform_type == 'rand_crop':
+                # crops differ per image but share their size: gather them, then one resize launch
+                crops = []
+                for j, (_, i, k) in enumerate(entries):
+                    x, y, cs = (int(v) for v in extra[(i, k)])
+                    crops.append(ops.crop(batch[j], (x, y, x + cs, y + cs)))
+                out = ops.resize(torch.stack(crops), (32, 32), ops.RESAMPLE_BICUBIC)
+            else:
+                out = tensor_fns[transform_type](batch, *args)
+            host = out.cpu().numpy()
+            for j, (_, i, k) in enumerate(entries):
+                results[i][k] = Image.fromarray(host[j])
+
+    transformed_images = []
+    for i, plan in enumerate(plans):
+        for k, (_, _, new_filename) in enumerate(plan):
+            if output_dir is not None:
+                results[i][k].save(os.path.join(output_dir, new_filename))
+            transformed_images.append(results[i][k])
+    return transformed_images

@@ -150,3 +150,27 @@ def test_error_paths(device):
     with pytest.raises(Exception):
         ops.perspective(t, [float("nan")] + ident[1:])
     assert ops.perspective(t[:0], ident).shape == (0, 8, 8, 3)
+
+
+def test_batched_twelve_transformation_driver_equals_per_image_driver(device):
+    """Same `random` / `np.random` / `torch` draws, same names and order, same pixels as the
+    per-image loop (fall_2025/transformations_code:68-155), for mixed image sizes."""
+    from imagetransformations_amd import transformations_code as TC
+    imgs = [(Image.fromarray(synth(70 + i, *hw)), f"cifar10_test_{i}_label_{i % 10}")
+            for i, hw in enumerate([(32, 32), (64, 64), (32, 32), (50, 61), (64, 64), (32, 32), (32, 32)])]   # rand_crop needs h >= int(0.78 w)
+    for seed in (0, 1):
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        a = TC.apply_all_transformations(imgs)
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        b = TC.apply_all_transformations_batched(imgs)
+        assert len(a) == len(b) == 12 * len(imgs)
+        for j, (x, y) in enumerate(zip(a, b)):
+            assert x.size == y.size and x.mode == y.mode, j
+            assert np.array_equal(np.asarray(x), np.asarray(y)), (seed, j, list(TC.TRANSFORMATIONS_2D)[j % 12])
+    # both drivers leave the three generators in the same state
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    TC.apply_all_transformations(imgs)
+    tail_a = (random.random(), float(np.random.rand()), float(torch.rand(1)))
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    TC.apply_all_transformations_batched(imgs)
+    assert tail_a == (random.random(), float(np.random.rand()), float(torch.rand(1)))
