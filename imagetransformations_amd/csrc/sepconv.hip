@@ -62,18 +62,29 @@ IMGXF_API int imgxf_sepconv_u8(const imgxf_view* src, const imgxf_view* dst, con
     return run_sepconv(src, dst, kx, nkx, ky, nky, border, dst_f32, stream);
 }
 
+// cv::getGaussianKernel: binomial kernels for sigma <= 0 and ksize in {1,3,5,7}
+static double small_gaussian_tab(int ksize, int i) {
+    static const double t3[3] = {0.25, 0.5, 0.25}, t5[5] = {0.0625, 0.25, 0.375, 0.25, 0.0625};
+    static const double t7[7] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
+    return ksize == 1 ? 1.0 : ksize == 3 ? t3[i] : ksize == 5 ? t5[i] : t7[i];
+}
+
 IMGXF_API int imgxf_gaussian_u8(const imgxf_view* src, const imgxf_view* dst, int ksize,
                                 double sigma, const imgxf_view* dst_f32, void* stream) {
     if (ksize < 1 || !(ksize & 1) || ksize > 31) return IMGXF_ERR_ARG;
-    if (sigma <= 0) sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8;
-    double kd[31], sum = 0.0;
-    for (int i = 0; i < ksize; ++i) {
-        const double x = i - (ksize - 1) * 0.5;
-        kd[i] = exp(-(x * x) / (2.0 * sigma * sigma));
-        sum += kd[i];
-    }
     float kf[31];
-    for (int i = 0; i < ksize; ++i) kf[i] = (float)(kd[i] / sum);
+    if (sigma <= 0 && ksize <= 7) {            // cv::getGaussianKernel's small_gaussian_tab
+        for (int i = 0; i < ksize; ++i) kf[i] = (float)small_gaussian_tab(ksize, i);
+    } else {
+        if (sigma <= 0) sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8;
+        double kd[31], sum = 0.0;
+        for (int i = 0; i < ksize; ++i) {
+            const double x = i - (ksize - 1) * 0.5;
+            kd[i] = exp(-(x * x) / (2.0 * sigma * sigma));
+            sum += kd[i];
+        }
+        for (int i = 0; i < ksize; ++i) kf[i] = (float)(kd[i] / sum);
+    }
     return run_sepconv(src, dst, kf, ksize, kf, ksize, IMGXF_BORDER_REFLECT_101, dst_f32, stream);
 }
 
@@ -99,6 +110,11 @@ IMGXF_API int imgxf_sepconv_fixed_u8(const imgxf_view* src, const imgxf_view* ds
 IMGXF_API int imgxf_gaussian_cv_fixed_u8(const imgxf_view* src, const imgxf_view* dst, int ksize,
                                          double sigma, void* stream) {
     if (ksize < 1 || !(ksize & 1) || ksize > 31) return IMGXF_ERR_ARG;
+    if (sigma <= 0 && ksize <= 7) {            // the binomial tables are exact multiples of 1/256
+        uint16_t kt[7];
+        for (int i = 0; i < ksize; ++i) kt[i] = (uint16_t)(small_gaussian_tab(ksize, i) * 256.0);
+        return imgxf_sepconv_fixed_u8(src, dst, kt, ksize, kt, ksize, IMGXF_BORDER_REFLECT_101, stream);
+    }
     if (sigma <= 0) sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8;
     // getGaussianKernelFixedPoint_ED: float kernel * 256, rounded with error diffusion from the
     // ends inward (round half to even), centre = 256 - the rest

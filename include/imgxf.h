@@ -69,7 +69,8 @@ int         imgxf_device_count(void);
 
 /* ---- a1: cv2.GaussianBlur(img,(k,k),sigma)  transformation.py:249 -------------------
  * Separable Gaussian, BORDER_REFLECT_101, fp32 accumulate, round-half-even, saturate.
- * c in {1,3,4}; ksize odd, 1..31.  sigma<=0 uses OpenCV's 0.3*((k-1)*0.5-1)+0.8.
+ * c in {1,3,4}; ksize odd, 1..31.  sigma<=0 as OpenCV: the binomial table for ksize <= 7,
+ * sigma = 0.3*((k-1)*0.5-1)+0.8 beyond.
  * `dst_f32` (optional, may be NULL): if given, a float view of the same n,h,w,c that
  * receives the pre-quantisation fp32 values (diagnostic; used by the parity tests). */
 int imgxf_gaussian_u8(const imgxf_view* src, const imgxf_view* dst, int ksize, double sigma,

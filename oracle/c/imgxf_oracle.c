@@ -51,13 +51,22 @@ int oracle_gaussian_blur_u8(const uint8_t* src, uint8_t* dst, double* tmp, int h
                             int ksize, double sigma) {
     if (ksize < 1 || !(ksize & 1) || ksize > 63) return -1;
     double k[63], sum = 0.0;
-    if (sigma <= 0) sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8;
-    for (int i = 0; i < ksize; ++i) {
-        double x = i - (ksize - 1) * 0.5;
-        k[i] = exp(-(x * x) / (2.0 * sigma * sigma));
-        sum += k[i];
+    /* cv::getGaussianKernel: binomial tables for sigma <= 0 and ksize <= 7 */
+    static const double tab3[3] = {0.25, 0.5, 0.25}, tab5[5] = {0.0625, 0.25, 0.375, 0.25, 0.0625};
+    static const double tab7[7] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
+    if (sigma <= 0 && ksize <= 7) {
+        const double* t = ksize == 3 ? tab3 : ksize == 5 ? tab5 : tab7;
+        if (ksize == 1) k[0] = 1.0; else memcpy(k, t, (size_t)ksize * sizeof(double));
+        sum = 1.0;
+    } else {
+        if (sigma <= 0) sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8;
+        for (int i = 0; i < ksize; ++i) {
+            double x = i - (ksize - 1) * 0.5;
+            k[i] = exp(-(x * x) / (2.0 * sigma * sigma));
+            sum += k[i];
+        }
+        for (int i = 0; i < ksize; ++i) k[i] /= sum;
     }
-    for (int i = 0; i < ksize; ++i) k[i] /= sum;
     const int r = ksize / 2;
     const int rb = w * c;
 #pragma omp parallel for schedule(static)

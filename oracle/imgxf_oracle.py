@@ -98,9 +98,22 @@ def blur_ksize(blur_radius):
     return ksize
 
 
+# cv::getGaussianKernel's fixed kernels for sigma <= 0 and ksize in {1, 3, 5, 7} (small_gaussian_tab)
+SMALL_GAUSSIAN_TAB = {
+    1: (1.0,),
+    3: (0.25, 0.5, 0.25),
+    5: (0.0625, 0.25, 0.375, 0.25, 0.0625),
+    7: (0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125),
+}
+
+
 def gaussian_kernel1d(ksize, sigma):
-    """cv::getGaussianKernel for sigma > 0: exp(-(i-(k-1)/2)^2 / (2 sigma^2)), normalised."""
+    """cv::getGaussianKernel: exp(-(i-(k-1)/2)^2 / (2 sigma^2)), normalised; sigma <= 0 takes the
+    binomial table for ksize <= 7 and sigma = 0.3*((k-1)*0.5-1)+0.8 beyond (the reference always
+    passes sigma = blur_radius > 0, transformation.py:249)."""
     if sigma <= 0:
+        if ksize in SMALL_GAUSSIAN_TAB:
+            return np.array(SMALL_GAUSSIAN_TAB[ksize], np.float64)
         sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
     x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
     k = np.exp(-(x * x) / (2.0 * sigma * sigma))
@@ -146,6 +159,10 @@ def gaussian_kernel_cv_fixed(ksize, sigma, bits=8):
     getGaussianKernelFixedPoint_ED): the float kernel times 2^bits, rounded with error diffusion
     from the ends inward, centre = 2^bits - the rest.  Restated from memory of OpenCV 4.x; double
     arithmetic stands in for its softdouble.  UNPINNED (no cv2 here) — see gaussian_blur_cv_fixed."""
+    if sigma <= 0:
+        if ksize in SMALL_GAUSSIAN_TAB:                       # exact multiples of 2^-bits
+            return np.array([int(v * (1 << bits)) for v in SMALL_GAUSSIAN_TAB[ksize]], np.int64)
+        sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
     n2 = (ksize - 1) // 2
     scale2x = -0.125 / (sigma * sigma)
     vals = [math.exp((x * x) * scale2x) for x in range(1 - ksize, 0, 2)][:n2]

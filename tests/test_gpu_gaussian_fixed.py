@@ -28,12 +28,11 @@ def test_gaussian_cv_fixed_matches_oracle(device, shape):
     h, w, c = shape
     a = synth(h * 7 + w, h, w, c)
     t = torch.from_numpy(a).to(device)
-    for ksize, sigma in ((3, 0.5), (5, 5 / 6), (7, 1.0), (9, 1.5), (13, 2.0), (19, 3.0), (31, 5.0), (5, 0.0), (1, 0.3)):
+    for ksize, sigma in ((3, 0.5), (5, 5 / 6), (7, 1.0), (9, 1.5), (13, 2.0), (19, 3.0), (31, 5.0), (5, 0.0), (7, -1.0), (9, 0.0), (1, 0.3)):
         if ksize // 2 + 1 > min(h, w):
             continue
-        sg = sigma if sigma > 0 else 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
         got = ops.gaussian_blur(t, ksize, sigma, fixed_point=True).cpu().numpy()
-        assert np.array_equal(got, O.gaussian_blur_cv_fixed(a, ksize, sg)), (shape, ksize, sigma)
+        assert np.array_equal(got, O.gaussian_blur_cv_fixed(a, ksize, sigma)), (shape, ksize, sigma)
 
 
 def test_fixed_taps_entry_point(device):
@@ -77,3 +76,16 @@ def test_facade_switch(device):
         T.BLUR_FIXED_POINT = False
     assert np.array_equal(got, O.gaussian_blur_cv_fixed(a, O.blur_ksize(1.5), 1.5))
     assert np.array_equal(np.asarray(T.apply_blur(img, 1.5)), O.apply_blur(a, 1.5))
+
+
+def test_float_path_with_sigma_not_given(device):
+    """sigma <= 0: OpenCV's binomial tables for ksize <= 7, its sigma formula beyond."""
+    from imagetransformations_amd import ops
+    for shape in ((64, 1024, 3), (37, 61, 3)):
+        a = synth(5, *shape)
+        t = torch.from_numpy(a).to(device)
+        for ksize in (3, 5, 7, 9, 15):
+            d = np.abs(ops.gaussian_blur(t, ksize, 0.0).cpu().numpy().astype(int) - O.gaussian_blur(a, ksize, 0.0).astype(int))
+            assert d.max() <= 1 and (d != 0).mean() < 1e-3, (shape, ksize)
+        # the 1-2-1 kernel has exact ties (x.5): both sides round half to even
+        assert np.array_equal(ops.gaussian_blur(t, 3, -1.0).cpu().numpy(), O.gaussian_blur(a, 3, -1.0))

@@ -239,3 +239,20 @@ def test_perspective_draws_follow_torch_generator():
         assert got == TV.coeffs(st, en)
         for p, (lo, hi) in zip(en, [((0, 0), (w // 2, h // 2)), ((w // 2, 0), (w, h // 2)), ((w // 2, h // 2), (w, h)), ((0, h // 2), (w // 2, h))]):
             assert lo[0] <= p[0] <= hi[0] and lo[1] <= p[1] <= hi[1]
+
+
+def test_opencv_small_gaussian_kernels():
+    """cv::getGaussianKernel's published fixed kernels for sigma <= 0 (small_gaussian_tab in
+    OpenCV's smooth code; the classic binomial 1-2-1, 1-4-6-4-1, ...-9-... / 32 rows) and the
+    documented sigma formula beyond ksize 7 — the only known-answer vectors OpenCV's own
+    documentation offers for this path without the library."""
+    assert list(O.gaussian_kernel1d(3, 0)) == [0.25, 0.5, 0.25]
+    assert list(O.gaussian_kernel1d(5, -1)) == [0.0625, 0.25, 0.375, 0.25, 0.0625]
+    assert list(O.gaussian_kernel1d(7, 0)) == [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]
+    assert list(O.gaussian_kernel_cv_fixed(5, 0)) == [16, 64, 96, 64, 16]
+    k9 = O.gaussian_kernel1d(9, 0)
+    s9 = 0.3 * ((9 - 1) * 0.5 - 1) + 0.8
+    assert np.allclose(k9, O.gaussian_kernel1d(9, s9), rtol=0, atol=0) and abs(k9.sum() - 1) < 1e-15
+    for k, s in ((5, 5 / 6), (13, 2.0), (31, 5.0)):
+        kf = O.gaussian_kernel_cv_fixed(k, s)
+        assert kf.sum() == 256 and (kf == kf[::-1]).all() and (np.abs(kf / 256 - O.gaussian_kernel1d(k, s)) < 1 / 256).all()
