@@ -1,0 +1,71 @@
+"""The float-tensor corruption maps of the reference's patch pipelines
+(/root/reference/pipenline/angellic.py:34-46, angellic2.py:47-50) on the HIP kernel
+`imgxf_f32_map`: same names, arguments and values (bit-identical to the torch expressions),
+differentiable like them — the reference applies them to patched images whose patch is being
+optimised, so a backward is provided (torch.clamp's rule: the gradient passes where the value
+before the clamp lay in [0, 1])."""
+from __future__ import annotations
+
+import torch
+
+from . import _ffi as F
+
+_BRIGHTNESS, _CONTRAST, _NOISE = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("tensor_maps run on the HIP device only (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected a float32 tensor, got {t.dtype}")
+    return t.contiguous()
+
+
+def _run(mode: int, x: torch.Tensor, noise, p0: float, p1: float, want_mask: bool):
+    out = torch.empty_like(x)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_mask else None
+    F.call("imgxf_f32_map", x.data_ptr(), noise.data_ptr() if noise is not None else None, out.data_ptr(),
+           mask.data_ptr() if mask is not None else None, x.numel(), mode, float(p0), float(p1), _stream())
+    return out, mask
+
+
+class _Map(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode, noise, p0, p1):
+        x = _check(x)
+        noise = _check(noise) if noise is not None else None
+        need = x.requires_grad
+        out, mask = _run(mode, x.detach(), noise, p0, p1, need)
+        if need:
+            ctx.save_for_backward(mask)
+            ctx.scale = p0 if mode == _CONTRAST else 1.0
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        gx = g * mask.to(g.dtype)
+        if ctx.scale != 1.0:
+            gx = gx * ctx.scale
+        return gx, None, None, None, None
+
+
+def add_gaussian_noise(images: torch.Tensor, mean: float = 0.0, std: float = 0.1) -> torch.Tensor:
+    """Apply Gaussian noise to unnormalized images [0,1] (angellic.py:34-37).  The draw is
+    torch.randn_like(images), as in the reference (same generator, same values)."""
+    noise = torch.randn_like(images)
+    return _Map.apply(images, _NOISE, noise, std, mean)
+
+
+def add_brightness(images: torch.Tensor, factor: float = 0.3) -> torch.Tensor:
+    """Add brightness to unnormalized images [0,1] (angellic.py:40-42)."""
+    return _Map.apply(images, _BRIGHTNESS, None, factor, 0.0)
+
+
+def add_contrast(images: torch.Tensor, factor: float = 1.5) -> torch.Tensor:
+    """Modify contrast of unnormalized images [0,1] (angellic.py:44-46)."""
+    return _Map.apply(images, _CONTRAST, None, factor, 0.0)

@@ -254,6 +254,17 @@ int imgxf_rot90_u8(const imgxf_view* src, const imgxf_view* dst, int quarter_tur
  * FLIP_TOP_BOTTOM (mode 1).  Same geometry in and out. */
 int imgxf_flip_u8(const imgxf_view* src, const imgxf_view* dst, int mode, void* stream);
 
+/* ---- float-tensor corruption maps  pipenline/angellic.py:34-46, angellic2.py:47-50 -------*/
+/* Unnormalised fp32 images in [0,1], any shape, `count` contiguous elements (device pointers,
+ * 4-byte aligned; in-place allowed).  mode BRIGHTNESS: clamp(x + p0, 0, 1); CONTRAST:
+ * clamp((x - 0.5)*p0 + 0.5, 0, 1); NOISE: clamp(x + (noise*p0 + p1), 0, 1) with `noise` the
+ * caller's torch.randn_like draw (std = p0, mean = p1).  Same fp32 operations in the same order as
+ * torch's eager kernels (bit-identical).  mask (optional, device, `count` bytes): 1 where the
+ * value before the clamp lay in [0,1], i.e. where torch.clamp's backward passes the gradient. */
+enum { IMGXF_F32_BRIGHTNESS = 0, IMGXF_F32_CONTRAST = 1, IMGXF_F32_NOISE = 2 };
+int imgxf_f32_map(const float* src, const float* noise, float* dst, uint8_t* mask, int64_t count,
+                  int mode, float p0, float p1, void* stream);
+
 /* ---- perspective warp  fall_2025/transformations_code:54-66 -----------------------------*/
 /* torchvision RandomPerspective on a float tensor for given coefficients: ToTensor (u8/255),
  * _perspective_grid + grid_sample(bilinear, padding zeros, align_corners=False) of the image and

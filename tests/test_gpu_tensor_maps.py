@@ -1,0 +1,72 @@
+"""GPU: the float-tensor corruption maps (pipenline/angellic.py:34-46) on `imgxf_f32_map` against
+the reference's own torch expressions — values bit-identical, gradients identical."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_noise(images, mean=0.0, std=0.1):
+    noise = torch.randn_like(images) * std + mean
+    return (images + noise).clamp(0, 1)
+
+
+def ref_brightness(images, factor=0.3):
+    return (images + factor).clamp(0, 1)
+
+
+def ref_contrast(images, factor=1.5):
+    return ((images - 0.5) * factor + 0.5).clamp(0, 1)
+
+
+@pytest.mark.parametrize("shape", [(128, 3, 32, 32), (7, 3, 33, 35), (1, 3, 1, 1), (5,), (2, 3, 224, 224)])
+def test_values_bit_identical(device, shape):
+    from imagetransformations_amd import tensor_maps as M
+    g = torch.Generator(device=device).manual_seed(1)
+    x = torch.rand(shape, device=device, generator=g) * 1.4 - 0.2        # some values outside [0,1]
+    for where in (device, "cpu"):                                         # torch's CUDA and CPU kernels agree with ours
+        xr = x.to(where)
+        for f in (0.3, -0.25, 0.0, 1e-3):
+            assert torch.equal(M.add_brightness(x, f).to(where), ref_brightness(xr, f)), ("brightness", f, where)
+        for f in (1.5, 0.5, 0.0, 2.75):
+            assert torch.equal(M.add_contrast(x, f).to(where), ref_contrast(xr, f)), ("contrast", f, where)
+    for mean, std in ((0.0, 0.1), (0.05, 0.3)):
+        torch.manual_seed(7)
+        got = M.add_gaussian_noise(x, mean, std)
+        torch.manual_seed(7)
+        assert torch.equal(got, ref_noise(x, mean, std))
+    assert torch.equal(M.add_brightness(x), ref_brightness(x)) and torch.equal(M.add_contrast(x), ref_contrast(x))
+    odd = torch.rand(4099, device=device)[3:]                              # 4-byte aligned only: scalar path
+    assert torch.equal(M.add_contrast(odd, 1.5), ref_contrast(odd, 1.5))
+    nan = torch.tensor([float("nan"), 0.5, -1.0, 2.0], device=device)
+    got = M.add_brightness(nan, 0.1)
+    assert torch.isnan(got[0]) and torch.equal(got[1:], ref_brightness(nan, 0.1)[1:])
+
+
+def test_gradients_follow_torch_clamp(device):
+    """angellic.py trains a patch through these maps: same gradient as autograd gives the
+    reference expressions, including the closed ends of clamp's pass-through interval."""
+    from imagetransformations_amd import tensor_maps as M
+    base = torch.tensor([-0.5, 0.0, 0.2, 0.5, 0.7, 1.0, 1.3, 0.25], device=device).repeat(33)
+    w = torch.linspace(-1, 1, base.numel(), device=device)
+    for ours, theirs, arg in ((M.add_brightness, ref_brightness, 0.3), (M.add_brightness, ref_brightness, 0.0),
+                              (M.add_contrast, ref_contrast, 1.5), (M.add_contrast, ref_contrast, 2.0)):
+        a = base.clone().requires_grad_(True)
+        b = base.clone().requires_grad_(True)
+        (ours(a, arg) * w).sum().backward()
+        (theirs(b, arg) * w).sum().backward()
+        assert torch.equal(a.grad, b.grad), (ours.__name__, arg)
+    a = base.clone().requires_grad_(True)
+    b = base.clone().requires_grad_(True)
+    torch.manual_seed(3); (M.add_gaussian_noise(a) * w).sum().backward()
+    torch.manual_seed(3); (ref_noise(b) * w).sum().backward()
+    assert torch.equal(a.grad, b.grad)
+
+
+def test_errors(device):
+    from imagetransformations_amd import tensor_maps as M
+    with pytest.raises(TypeError):
+        M.add_brightness(torch.zeros(4, device=device, dtype=torch.float64))
+    with pytest.raises(RuntimeError):
+        M.add_brightness(torch.zeros(4))
+    assert M.add_contrast(torch.zeros((0, 3, 32, 32), device=device)).shape == (0, 3, 32, 32)
