@@ -16,11 +16,11 @@ if not _building:
     from . import _ffi  # noqa: F401  (raises ImportError / AttributeError when the HIP library is missing or stale)
 
 __version__ = "0.1.0"
-__all__ = ["ops", "transformation", "transformations_code", "pool", "augmix", "tensor_maps", "sharding", "_ffi"]
+__all__ = ["ops", "transformation", "transformations_code", "pool", "augmix", "tensor_maps", "io_pipeline", "sharding", "_ffi"]
 
 
 def __getattr__(name):
-    if name in ("ops", "transformation", "transformations_code", "sharding", "pool", "augmix", "tensor_maps"):
+    if name in ("ops", "transformation", "transformations_code", "sharding", "pool", "augmix", "tensor_maps", "io_pipeline"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

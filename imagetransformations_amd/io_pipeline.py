@@ -1,0 +1,70 @@
+"""The on-disk steps either side of the hot path (/root/reference/transformation.py:73-89 load,
+:159-162 save) as a streaming pipeline around the batched driver: JPEG decode and encode stay on
+the CPU with Pillow — the same codec the reference uses, so the pixels entering and leaving are the
+reference's — but run in worker threads (Pillow releases the GIL inside the codecs) that overlap
+with the GPU work of the neighbouring chunks:
+
+    decode chunk k+1  |  transform chunk k on the GPU  |  encode + write chunk k-1
+
+Chunks are consecutive slices of the file list in the reference's order, and the batched driver
+draws per image in list order, so the `random` / `np.random` streams — hence file names and pixels
+— are those of the reference's one-image-at-a-time loop."""
+from __future__ import annotations
+
+import os
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, Iterable, List, Sequence, Tuple
+
+from PIL import Image
+
+
+def list_images(data_path: str, suffix: str = ".jpeg") -> List[str]:
+    """The file order of the reference's load_data (:74-78): os.walk order, *.jpeg, case-insensitive."""
+    paths = []
+    for root, _, files in os.walk(data_path):
+        paths.extend(os.path.join(root, f) for f in files if f.lower().endswith(suffix))
+    return paths
+
+
+def _decode(path: str):
+    try:
+        return Image.open(path).convert("RGB"), path          # :83
+    except Exception as e:                                     # the reference guards only the loading (:85-86)
+        print(f"Failed to load image {path}: {e}")
+        return None
+
+
+def _chunks(seq: Sequence, n: int) -> Iterable[Sequence]:
+    for i in range(0, len(seq), n):
+        yield seq[i:i + n]
+
+
+def run_directory(data_path: str, out_dir: str, chunk_images: int = 256, workers: int = 8,
+                  transform: Callable[[List[Tuple[Image.Image, str]]], List[Tuple[str, Image.Image]]] | None = None) -> int:
+    """load_data + apply_all_transformations + save over a directory, streamed.  `transform` maps a
+    chunk [(image, path)] to [(file name, image)] in output order; default: the batched
+    eight-transformation driver.  Returns the number of files written."""
+    if transform is None:
+        from .transformation import apply_all_transformations_batched_named as transform
+    os.makedirs(out_dir, exist_ok=True)
+    chunk_paths = list(_chunks(list_images(data_path), chunk_images))
+    written = 0
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        decoding = pool.map(_decode, chunk_paths[0]) if chunk_paths else None
+        saving = []
+        for k in range(len(chunk_paths)):
+            chunk = [d for d in decoding if d is not None]
+            if k + 1 < len(chunk_paths):                        # the next chunk decodes while this one is on the GPU
+                decoding = pool.map(_decode, chunk_paths[k + 1])
+            named = transform(chunk) if chunk else []
+            for fut in saving:                                  # chunk k-1 has been encoding meanwhile
+                fut.result()
+            saving = [pool.submit(_save, img, os.path.join(out_dir, name)) for name, img in named]
+            written += len(named)
+        for fut in saving:
+            fut.result()
+    return written
+
+
+def _save(img: Image.Image, path: str) -> None:
+    img.save(path)                                              # Image.save defaults, as :162

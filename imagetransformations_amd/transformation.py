@@ -285,7 +285,18 @@ def apply_all_transformations(images):
 
 
 def apply_all_transformations_batched(images):
-    """`apply_all_transformations` with the work grouped for the GPU: same draws (`random` per
+    """`apply_all_transformations_batched_named` + the reference's save step (:159-162)."""
+    transformed_images = []
+    for new_filename, img in apply_all_transformations_batched_named(images):
+        if output_dir is not None:
+            img.save(os.path.join(output_dir, new_filename))
+        transformed_images.append(img)
+    return transformed_images
+
+
+def apply_all_transformations_batched_named(images):
+    """`apply_all_transformations` with the work grouped for the GPU, returning
+    [(file name, image)] in the reference's output order and saving nothing: same draws (`random` per
     transform type per image, `np.random` for the noise, in the reference's order), same file
     names, same outputs in the same order — but every image is uploaded once, and all images
     of one size that drew the same (type, value) go through ONE batched launch.  Images that
@@ -346,10 +357,4 @@ def apply_all_transformations_batched(images):
             for j, (_, i, k) in enumerate(entries):
                 results[i][k] = Image.fromarray(host[j])
 
-    transformed_images = []
-    for i, plan in enumerate(plans):
-        for k, (_, _, new_filename) in enumerate(plan):
-            if output_dir is not None:
-                results[i][k].save(os.path.join(output_dir, new_filename))
-            transformed_images.append(results[i][k])
-    return transformed_images
+    return [(new_filename, results[i][k]) for i, plan in enumerate(plans) for k, (_, _, new_filename) in enumerate(plan)]

@@ -1,0 +1,77 @@
+"""The streaming load -> transform -> save pipeline (imagetransformations_amd/io_pipeline.py):
+file order, chunking, overlap bookkeeping and error handling on the CPU with a stand-in transform;
+on the GPU the real batched driver against the per-image driver, file for file."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import synth
+
+Image = pytest.importorskip("PIL.Image")
+
+
+def _make_tree(root, n=11):
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(n):
+        d = os.path.join(root, f"n{i % 3:02d}")
+        os.makedirs(d, exist_ok=True)
+        p = os.path.join(d, f"img_{i}.JPEG")
+        hw = [(32, 32), (48, 64), (37, 61)][i % 3]
+        Image.fromarray(synth(i, *hw)).save(p, quality=95)
+        paths.append(p)
+    with open(os.path.join(root, "n00", "broken.jpeg"), "wb") as fh:
+        fh.write(b"not a jpeg")
+    with open(os.path.join(root, "n00", "notes.txt"), "w") as fh:
+        fh.write("ignored")
+    return paths
+
+
+def test_streaming_order_and_chunking(tmp_path, capsys):
+    from imagetransformations_amd import io_pipeline as IO
+    src, dst = str(tmp_path / "in"), str(tmp_path / "out")
+    _make_tree(src)
+    order = IO.list_images(src)
+    assert len(order) == 12 and all(p.lower().endswith(".jpeg") for p in order)
+    seen = []
+
+    def fake(chunk):
+        seen.append([os.path.basename(p) for _, p in chunk])
+        return [(os.path.splitext(os.path.basename(p))[0] + "_copy.jpg", img) for img, p in chunk]
+
+    for chunk_images in (1, 4, 5, 100):
+        seen.clear()
+        n = IO.run_directory(src, dst, chunk_images=chunk_images, workers=3, transform=fake)
+        assert n == 11                                              # the broken file is reported and skipped
+        flat = [b for c in seen for b in c]
+        assert flat == [os.path.basename(p) for p in order if "broken" not in p]
+        assert all(len(c) <= chunk_images for c in seen)
+        assert sorted(os.listdir(dst)) == sorted(os.path.splitext(b)[0] + "_copy.jpg" for b in flat)
+    assert "Failed to load image" in capsys.readouterr().out
+    assert IO.run_directory(str(tmp_path / "empty"), dst, transform=fake) == 0
+
+
+@pytest.mark.gpu
+def test_streamed_directory_equals_per_image_driver(device, tmp_path):
+    from imagetransformations_amd import io_pipeline as IO, transformation as T
+    src, dst = str(tmp_path / "in"), str(tmp_path / "out")
+    _make_tree(src)
+    random.seed(5); np.random.seed(5)
+    n = IO.run_directory(src, dst, chunk_images=4, workers=4)
+    assert n == 8 * 11
+    random.seed(5); np.random.seed(5)
+    imgs = [(Image.open(p).convert("RGB"), p) for p in IO.list_images(src) if "broken" not in p]
+    want = []
+    for img, path in imgs:
+        name = os.path.splitext(os.path.basename(path))[0]
+        for ttype, args, fname in T.plan_transformations(name):
+            fn = T.apply_translation if ttype == "translation" else T._DISPATCH[ttype]
+            want.append((fname, fn(img, *args)))
+    assert sorted(os.listdir(dst)) == sorted(f for f, _ in want)
+    for fname, img in want:
+        got = np.asarray(Image.open(os.path.join(dst, fname)).convert("RGB"))
+        import io as _io
+        buf = _io.BytesIO(); img.save(buf, format="JPEG")
+        assert np.array_equal(got, np.asarray(Image.open(_io.BytesIO(buf.getvalue())).convert("RGB"))), fname
