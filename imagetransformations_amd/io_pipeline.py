@@ -68,3 +68,38 @@ def run_directory(data_path: str, out_dir: str, chunk_images: int = 256, workers
 
 def _save(img: Image.Image, path: str) -> None:
     img.save(path)                                              # Image.save defaults, as :162
+
+
+SEVERITY_INDICES = [0, 1001, 2002, 3003, 4004, 10000, 10001, 12002, 13003, 14004, 15005, 20000, 22002, 23003,
+                    24004, 25005, 30000, 40000]          # transformation.py:28 (zip with five labels uses the first five)
+SEVERITY_LABELS = [1, 2, 3, 4, 5]
+
+
+def load_data_npy(data_path: str, store_dir: str) -> int:
+    """The CIFAR-10-C extraction step (transformation.py:20-71): every *.npy under `data_path`
+    with shape (50000, 32, 32, 3) contributes the images at the first five severity indices,
+    written as `{corruption}_severity{level}_idx{index}.png`.  The arrays are memory-mapped
+    (153 MB each; five 3 KiB slices are read), the bytes written are the reference's."""
+    import numpy as np
+    os.makedirs(store_dir, exist_ok=True)
+    npy_files = []
+    for root, _, files in os.walk(data_path):
+        npy_files.extend(os.path.join(root, f) for f in files if f.lower().endswith('.npy'))
+    extracted_count = 0
+    for file_path in npy_files:
+        try:
+            corruption_data = np.load(file_path, mmap_mode="r")
+            corruption_name = os.path.splitext(os.path.basename(file_path))[0]
+            if corruption_data.shape != (50000, 32, 32, 3):
+                print(f"  Warning: Unexpected shape for {corruption_name}.npy: {corruption_data.shape}. Skipping.")
+                continue
+            for s_idx, severity_level in zip(SEVERITY_INDICES, SEVERITY_LABELS):
+                img_array = np.array(corruption_data[s_idx])
+                if img_array.dtype != np.uint8:
+                    img_array = img_array.astype(np.uint8)
+                Image.fromarray(img_array).save(
+                    os.path.join(store_dir, f"{corruption_name}_severity{severity_level}_idx{s_idx}.png"))
+                extracted_count += 1
+        except Exception as e:
+            print(f"Failed to process file {file_path}: {e}")
+    return extracted_count
