@@ -85,6 +85,7 @@ SIGNATURES = {
     "imgxf_rot90_u8": [_VP, _VP, C.c_int, C.c_void_p],
     "imgxf_flip_u8": [_VP, _VP, C.c_int, C.c_void_p],
     "imgxf_f32_map": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p],
+    "imgxf_to_tensor_f32": [_VP, C.c_void_p, _F, _F, C.c_void_p],
     "imgxf_perspective_bilinear_u8": [_VP, _VP, C.POINTER(C.c_float), C.c_int, C.c_void_p],
     "imgxf_histogram_u8": [_VP, C.c_void_p, C.c_void_p],
     "imgxf_percentile_mask_u8": [_VP, C.c_void_p, C.c_double, _VP, C.c_void_p, C.c_void_p],

@@ -62,9 +62,67 @@ static int launch_f32_map(const float* src, const float* noise, float* dst, u8* 
     return launch_status();
 }
 
+// ToTensor (+ Normalize): uint8 HWC -> float32 CHW, x/255 correctly rounded (Tensor.div(255)),
+// then (x - mean[c]) / std[c] as two fp32 operations (Tensor.sub_ / div_), the model-input step
+// that follows the transformations in every evaluation script of the reference
+// (e.g. fall_2025/transformations_code:57 ToTensor; T.Normalize at 68 call sites).
+struct NormArgs { float mean[4], std[4]; int normalize; };
+
+__device__ __forceinline__ float unit255f(u32 b) {
+    const float v = (float)b, r = __uint_as_float(0x3b808081u);      // RN(1/255); one residual step makes it exact
+    const float q = v * r;
+    return fmaf(fmaf(-255.0f, q, v), r, q);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void to_tensor_kernel(View s, float* __restrict__ dst, NormArgs a) {
+    const int64_t plane = (int64_t)s.h * s.w;
+    const int64_t total = (int64_t)s.n * plane;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % s.w);
+        const int64_t r = i / s.w;
+        const int y = (int)(r % s.h), f = (int)(r / s.h);
+        const u8* sp = s.row(f, y) + (int64_t)x * C;
+        float* dp = dst + (int64_t)f * C * plane + (int64_t)y * s.w + x;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float v = unit255f(sp[c]);
+            if (a.normalize) v = (v - a.mean[c]) / a.std[c];
+            dp[c * plane] = v;
+        }
+    }
+}
+
 } // namespace imgxf
 
 using namespace imgxf;
+
+IMGXF_API int imgxf_to_tensor_f32(const imgxf_view* src, float* dst, const float* mean, const float* std,
+                                  void* stream) {
+    IMGXF_CHECK(check_view(src));
+    if (empty_view(src)) return IMGXF_OK;
+    if (!dst) return IMGXF_ERR_NULL;
+    if (((uintptr_t)dst) & 3) return IMGXF_ERR_ARG;
+    if ((mean == nullptr) != (std == nullptr)) return IMGXF_ERR_NULL;
+    if (src->c == 2) return IMGXF_ERR_UNSUPPORTED;
+    NormArgs a;
+    a.normalize = mean != nullptr;
+    for (int c = 0; c < 4; ++c) {
+        a.mean[c] = a.normalize && c < src->c ? mean[c] : 0.0f;
+        a.std[c] = a.normalize && c < src->c ? std[c] : 1.0f;
+    }
+    const View s = make_view(src);
+    const int64_t total = (int64_t)s.n * s.h * s.w;
+    int64_t blocks = (total + 255) / 256;
+    blocks = blocks > 65536 ? 65536 : blocks;
+    hipStream_t st = (hipStream_t)stream;
+    switch (s.c) {
+        case 1: hipLaunchKernelGGL(to_tensor_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, s, dst, a); break;
+        case 3: hipLaunchKernelGGL(to_tensor_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, s, dst, a); break;
+        case 4: hipLaunchKernelGGL(to_tensor_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, s, dst, a); break;
+    }
+    return launch_status();
+}
 
 IMGXF_API int imgxf_f32_map(const float* src, const float* noise, float* dst, uint8_t* mask,
                             int64_t count, int mode, float p0, float p1, void* stream) {

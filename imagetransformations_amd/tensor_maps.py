@@ -69,3 +69,21 @@ def add_brightness(images: torch.Tensor, factor: float = 0.3) -> torch.Tensor:
 def add_contrast(images: torch.Tensor, factor: float = 1.5) -> torch.Tensor:
     """Modify contrast of unnormalized images [0,1] (angellic.py:44-46)."""
     return _Map.apply(images, _CONTRAST, None, factor, 0.0)
+
+
+def to_tensor(frames: torch.Tensor, mean=None, std=None) -> torch.Tensor:
+    """transforms.ToTensor() followed (when mean / std are given) by transforms.Normalize(mean, std)
+    on a uint8 [N,H,W,C] / [H,W,C] / [H,W] device tensor -> float32 [N,C,H,W] / [C,H,W], in one
+    pass and bit-identical to torchvision's `x.div(255)`, `sub_(mean)`, `div_(std)`."""
+    if not frames.is_cuda or frames.dtype != torch.uint8:
+        raise TypeError("to_tensor expects a uint8 tensor on the HIP device")
+    if (mean is None) != (std is None):
+        raise ValueError("mean and std come together")
+    v = F.view_of(frames)
+    n, h, w, c = v.n, v.h, v.w, v.c
+    if mean is not None and (len(mean) != c or len(std) != c):
+        raise ValueError(f"mean / std need {c} entries")
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=frames.device)
+    F.call("imgxf_to_tensor_f32", F.vp(v), out.data_ptr(), F.f32_array(mean) if mean is not None else None,
+           F.f32_array(std) if std is not None else None, _stream())
+    return out if frames.dim() == 4 else out[0]

@@ -265,6 +265,13 @@ enum { IMGXF_F32_BRIGHTNESS = 0, IMGXF_F32_CONTRAST = 1, IMGXF_F32_NOISE = 2 };
 int imgxf_f32_map(const float* src, const float* noise, float* dst, uint8_t* mask, int64_t count,
                   int mode, float p0, float p1, void* stream);
 
+/* transforms.ToTensor() (+ transforms.Normalize(mean, std)): uint8 HWC frames -> float32
+ * [n][c][h][w] planes at `dst` (device, contiguous), x/255 correctly rounded, then
+ * (x - mean[c]) / std[c] in fp32 — bit-identical to torchvision's tensor arithmetic.  mean / std:
+ * HOST float[c], both NULL = ToTensor only.  c in {1,3,4}. */
+int imgxf_to_tensor_f32(const imgxf_view* src, float* dst, const float* mean, const float* std,
+                        void* stream);
+
 /* ---- perspective warp  fall_2025/transformations_code:54-66 -----------------------------*/
 /* torchvision RandomPerspective on a float tensor for given coefficients: ToTensor (u8/255),
  * _perspective_grid + grid_sample(bilinear, padding zeros, align_corners=False) of the image and

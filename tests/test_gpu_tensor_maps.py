@@ -70,3 +70,29 @@ def test_errors(device):
     with pytest.raises(RuntimeError):
         M.add_brightness(torch.zeros(4))
     assert M.add_contrast(torch.zeros((0, 3, 32, 32), device=device)).shape == (0, 3, 32, 32)
+
+
+@pytest.mark.parametrize("shape", [(5, 32, 32, 3), (2, 37, 61, 3), (224, 224, 3), (3, 17, 9, 1), (19, 23), (2, 8, 8, 4)])
+def test_to_tensor_normalize_bit_identical(device, shape):
+    """ToTensor + Normalize as torchvision computes them in the reference's dataset transforms, i.e.
+    on the CPU: div(255) (a true division there; torch's CUDA div multiplies by a reciprocal and is
+    1 ulp off for some bytes), sub_(mean), div_(std) in fp32."""
+    from imagetransformations_amd import tensor_maps as M
+    g = torch.Generator(device=device).manual_seed(2)
+    u = torch.randint(0, 256, shape, dtype=torch.uint8, device=device, generator=g)
+    c = 1 if len(shape) == 2 else shape[-1]
+    uc = u.cpu()
+    chw = uc if len(shape) == 2 else uc.movedim(-1, -3)
+    want = chw.contiguous().to(torch.float32).div(255)
+    if len(shape) == 2:
+        want = want.unsqueeze(0)
+    got = M.to_tensor(u)
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)
+    mean, std = [0.4914, 0.4822, 0.4465, 0.5][:c], [0.2470, 0.2435, 0.2616, 0.25][:c]
+    mt = torch.as_tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+    st = torch.as_tensor(std, dtype=torch.float32).view(-1, 1, 1)
+    assert torch.equal(M.to_tensor(u, mean, std).cpu(), want.clone().sub_(mt).div_(st))
+    wide = torch.zeros(shape[:-2] + (shape[-2] + 5, shape[-1]) if len(shape) > 2 else (shape[0], shape[1] + 5), dtype=torch.uint8, device=device)
+    view = wide[..., 2:2 + shape[-2], :] if len(shape) > 2 else wide[:, 2:2 + shape[1]]
+    view.copy_(u)
+    assert torch.equal(M.to_tensor(view).cpu(), want)            # strided rows
