@@ -87,3 +87,31 @@ def to_tensor(frames: torch.Tensor, mean=None, std=None) -> torch.Tensor:
     F.call("imgxf_to_tensor_f32", F.vp(v), out.data_ptr(), F.f32_array(mean) if mean is not None else None,
            F.f32_array(std) if std is not None else None, _stream())
     return out if frames.dim() == 4 else out[0]
+
+
+def resized_output_size(height: int, width: int, size: int):
+    """torchvision.transforms.functional._compute_resized_output_size for an int `size` (no
+    max_size): the shorter edge becomes `size`, the longer int(size * long / short)."""
+    short, long = (width, height) if width <= height else (height, width)
+    new_short, new_long = size, int(size * long / short)
+    return (new_long, new_short) if width <= height else (new_short, new_long)      # (new_h, new_w)
+
+
+def preprocess(frames: torch.Tensor, resize: int = 256, crop: int = 224, mean=None, std=None) -> torch.Tensor:
+    """transforms.Compose([Resize(resize), CenterCrop(crop), ToTensor(), Normalize(mean, std)]) on
+    uint8 [N,H,W,C] / [H,W,C] device frames — the evaluation preprocessing of the reference's
+    ImageNet scripts (Resize(256), CenterCrop(224)) — as Pillow / torchvision compute it on PIL
+    images: BILINEAR `Image.resize` of the shorter edge (only the crop window is filtered),
+    crop offsets int(round((h - crop) / 2.0)), then `to_tensor`."""
+    from . import ops
+    h, w = (frames.shape[-3], frames.shape[-2])
+    nh, nw = resized_output_size(h, w, resize)
+    if crop > nh or crop > nw:
+        raise ValueError("CenterCrop larger than the resized image (torchvision pads; not needed by the reference)")
+    top, left = int(round((nh - crop) / 2.0)), int(round((nw - crop) / 2.0))
+    box = (left, top, left + crop, top + crop)
+    if (nh, nw) == (h, w):                                   # Resize returns the image itself
+        t = ops.crop(frames, box)
+    else:
+        t = ops.resize_crop(frames, (nw, nh), box, ops.RESAMPLE_BILINEAR)
+    return to_tensor(t, mean, std)
