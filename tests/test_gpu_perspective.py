@@ -174,3 +174,40 @@ def test_batched_twelve_transformation_driver_equals_per_image_driver(device):
     random.seed(5); np.random.seed(5); torch.manual_seed(5)
     TC.apply_all_transformations_batched(imgs)
     assert tail_a == (random.random(), float(np.random.rand()), float(torch.rand(1)))
+
+
+def test_new_entry_points_are_stream_capturable(device):
+    """perspective warp (per-frame coefficients travel as kernel arguments), the fixed-point
+    Gaussian and ToTensor+Normalize captured into one HIP graph and replayed on new input."""
+    from imagetransformations_amd import _ffi
+    n, h, w = 6, 48, 64
+    batch = np.stack([synth(300 + i, h, w) for i in range(n)])
+    src = torch.from_numpy(batch).to(device)
+    a, b = torch.empty_like(src), torch.empty_like(src)
+    out = torch.empty((n, 3, h, w), dtype=torch.float32, device=device)
+    coeffs = _ffi.f32_array([v for i in range(n) for v in _coeffs(w, h, 0.2, i)])
+    mean, std = _ffi.f32_array([0.5, 0.4, 0.3]), _ffi.f32_array([0.2, 0.25, 0.3])
+
+    def chain(stream):
+        _ffi.call("imgxf_perspective_bilinear_u8", _ffi.vp(_ffi.view_of(src)), _ffi.vp(_ffi.view_of(a)), coeffs, 1, stream)
+        _ffi.call("imgxf_gaussian_cv_fixed_u8", _ffi.vp(_ffi.view_of(a)), _ffi.vp(_ffi.view_of(b)), 5, 5.0 / 6.0, stream)
+        _ffi.call("imgxf_to_tensor_f32", _ffi.vp(_ffi.view_of(b)), out.data_ptr(), mean, std, stream)
+
+    chain(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = out.clone()
+    out.zero_()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            chain(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert not torch.equal(out, want)
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    src.copy_(torch.from_numpy(batch[::-1].copy()).to(device))
+    g.replay(); torch.cuda.synchronize()
+    got = out.clone()
+    chain(torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+    assert torch.equal(got, out) and not torch.equal(got, want)
