@@ -89,3 +89,23 @@ def test_float_path_with_sigma_not_given(device):
             assert d.max() <= 1 and (d != 0).mean() < 1e-3, (shape, ksize)
         # the 1-2-1 kernel has exact ties (x.5): both sides round half to even
         assert np.array_equal(ops.gaussian_blur(t, 3, -1.0).cpu().numpy(), O.gaussian_blur(a, 3, -1.0))
+
+
+@pytest.mark.parametrize("w", [96, 112, 176, 336, 352, 1280, 2000])
+def test_large_kernels_across_strip_geometries(device, w):
+    """k >= 11 on RGB takes the pixel-stride marching kernel (252-byte strips, 21 pixel groups per
+    wave): widths around the strip boundaries, several frames, fixed-point bit for bit and the float
+    path to 1e-5 relative before rounding."""
+    from imagetransformations_amd import ops
+    h = 70
+    frames = np.stack([synth(w + i, h, w) for i in range(3)])
+    t = torch.from_numpy(frames).to(device)
+    for ksize, sigma in ((11, 11 / 6), (13, 2.0), (17, 2.9), (21, 3.5), (25, 4.0), (31, 5.0)):
+        if w * 3 < 256 + 32 * ((ksize // 2 * 3 + 15) // 16):
+            continue
+        got = ops.gaussian_blur(t, ksize, sigma, fixed_point=True).cpu().numpy()
+        out, f32 = ops.gaussian_blur(t, ksize, sigma, return_f32=True)
+        for i in range(3):
+            assert np.array_equal(got[i], O.gaussian_blur_cv_fixed(frames[i], ksize, sigma)), (w, ksize, i)
+            ref = O.gaussian_blur_f64(frames[i], ksize, sigma)
+            assert (np.abs(f32[i].cpu().numpy() - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0)).all(), (w, ksize, i)

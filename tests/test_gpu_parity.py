@@ -413,6 +413,9 @@ h, w = a.shape[:2]
 g, f32 = ops.gaussian_blur(t, 5, 5 / 6, return_f32=True)
 ref = O.gaussian_blur_f64(a, 5, 5 / 6)
 assert (np.abs(f32.cpu().numpy() - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0)).all(), "gaussian"
+g13, f13 = ops.gaussian_blur(t, 13, 2.0, return_f32=True)
+ref13 = O.gaussian_blur_f64(a, 13, 2.0)
+assert (np.abs(f13.cpu().numpy() - ref13) <= 1e-5 * np.maximum(np.abs(ref13), 1.0)).all(), "gaussian k=13"
 m = O.rotate_zoom_matrix(w, h, 30.0, 1.5)
 assert np.array_equal(ops.affine(t, m, (w, h), ops.BILINEAR, (0, 0, 0), precise=True).cpu().numpy(),
                       O.affine_bilinear(a, (w, h), m, fill=(0, 0, 0))), "bilinear"
@@ -424,7 +427,7 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("knob", ["IMGXF_NO_MARCH", "IMGXF_AFFINE_NO_LDS", "IMGXF_AFFINE_NO_DMA", "IMGXF_LANCZOS_SLOW", "IMGXF_LANCZOS_NO_LDS", "IMGXF_LANCZOS_NO_V4", "IMGXF_AFFINE_NO_TALL"])
+@pytest.mark.parametrize("knob", ["IMGXF_NO_MARCH", "IMGXF_AFFINE_NO_LDS", "IMGXF_AFFINE_NO_DMA", "IMGXF_LANCZOS_SLOW", "IMGXF_LANCZOS_NO_LDS", "IMGXF_LANCZOS_NO_V4", "IMGXF_AFFINE_NO_TALL", "IMGXF_MARCH4_NO_PX"])
 def test_general_kernels_behind_the_tuning_knobs(device, knob):
     """The environment knobs route aligned inputs to the general kernels (LDS-tiled separable
     filter, global-gather affine, dword-staged nearest, per-tap Lanczos); each must hold the
