@@ -515,7 +515,8 @@ __device__ __forceinline__ bool bilinear_tile(const View& s, const View& d, cons
     // interior tile (block-uniform): inside the output, and the 2x2 support of every pixel inside the source
     const bool clean = ux_lo >= 0 && uy_lo >= 0 && (int)(xhi >> 40) + 1 <= s.w - 1 && (int)(yhi >> 40) + 1 <= s.h - 1 &&
                        txb * BW + BW <= d.w && tyb * BH + BH <= d.h;
-    if (INTERIOR && !clean) return false;
+    // (INTERIOR: the one tile whose box holds the frame's last pixel is left to the list kernel too — same test as the host's)
+    if (INTERIOR && (!clean || ((int)(xhi >> 40) + 1 == s.w - 1 && (int)(yhi >> 40) + 1 == s.h - 1))) return false;
 
     // ---- stage the bounding box: wave w copies rows w, w+4, ...; lanes walk consecutive pixels
     // of a source row (unaligned 4-byte loads at a 3-byte lane stride: two cache lines per
@@ -1279,6 +1280,10 @@ static int launch_affine_filter(int filter, const View& s, const View& d, const 
     return launch_status();
 }
 
+} // namespace imgxf
+#include "affine_mf.inc"
+namespace imgxf {
+
 // Tall interior tiles: `affine_bilinear_lds_interior_kernel<.., BHT>` over every 32 x BHT tile (the
 // ones that are not interior leave at once) and `affine_bilinear_lds_list_kernel` over the host's
 // list of those that are not.  Returns BILINEAR_TALL_NOT_TAKEN when the taller tile's source box
@@ -1305,7 +1310,8 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
             const int64_t YT = P.y00 + (int64_t)(tx * 32) * P.q3 + (int64_t)(ty * BHT) * P.q4;
             const bool clean = (int)((XT + xlo_o) >> 40) >= 0 && (int)((YT + ylo_o) >> 40) >= 0 &&
                                (int)((XT + xhi_o) >> 40) + 1 <= s.w - 1 && (int)((YT + yhi_o) >> 40) + 1 <= s.h - 1 &&
-                               tx * 32 + 32 <= d.w && ty * BHT + BHT <= d.h;
+                               tx * 32 + 32 <= d.w && ty * BHT + BHT <= d.h &&
+                               !((int)((XT + xhi_o) >> 40) + 1 == s.w - 1 && (int)((YT + yhi_o) >> 40) + 1 == s.h - 1);
             if (!clean) {
                 if (list.n < BILINEAR_LIST_MAX) list.idx[list.n] = (u32)(ty * ntx + tx);
                 ++list.n;
@@ -1313,7 +1319,36 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
         }
     if (list.n > BILINEAR_LIST_MAX) return BILINEAR_TALL_NOT_TAKEN;
     const bool want_f32 = dbg.p != nullptr;
-    if (list.n < ntx * ntyt) {                       // at least one interior tile
+    // batches: the interior tiles loop over `fpb` frames per workgroup with the per-pixel geometry
+    // held in registers (affine_mf.inc); single frames and the fp32 side output keep the per-frame kernel
+    const char* fpb_env = getenv("IMGXF_AFFINE_FPB");
+    const int fpb = fpb_env ? atoi(fpb_env) : 8;
+    const int afpb = fpb < 0 ? -fpb : fpb;
+    const bool mf = BHT == MF_TILE_H && !want_f32 && afpb >= 2 && d.n >= 2 && bht <= 64 &&
+                    (int64_t)d.h * d.rs < ((int64_t)1 << 32);
+    if (list.n < ntx * ntyt && mf) {
+        const dim3 grid((unsigned)(ntx * ntyt), (unsigned)((d.n + afpb - 1) / afpb));
+        // LDS-DMA staging of packed rows needs 16-byte aligned source rows and a box of <= 52 x 52 pixels
+        const int nch = (bwt * 3 + 15 + 15) / 16;              // 16-byte chunks per packed box row (any alignment of its start)
+        const bool dma = getenv("IMGXF_AFFINE_NO_DMA") == nullptr && bht <= 52 && bwt <= 52 && 52 * nch <= 768 &&
+                         ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 15) == 0 && s.w * 3 >= 16 &&
+                         (int64_t)s.h * s.rs < ((int64_t)1 << 32);
+        if (dma) {
+            const size_t lds = (size_t)52 * 56 * 4 + 2 * ((size_t)52 * nch * 16 + 64);   // RGBX pitch 56: fewest bank conflicts of the multiples of 4 (simulated: 4.0 vs 5.8 LDS cycles per gather read at pitch 52)
+            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch);
+            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch);
+        } else {
+            const size_t lds = (size_t)2 * PITCH * (bht <= 52 ? 52 : 64) * 4 + 16;     // all 4 * NBR rows are written
+            if (bht <= 52) {
+                if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
+                else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
+            } else {
+                if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
+                else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
+            }
+        }
+        IMGXF_CHECK(launch_status());
+    } else if (list.n < ntx * ntyt) {                // at least one interior tile
         const dim3 grid((unsigned)(ntx * ntyt), (unsigned)d.n);
         const size_t lds = (size_t)PITCH * bht * 4 + 16;
         if (pr && want_f32) hipLaunchKernelGGL((affine_bilinear_lds_interior_kernel<true, PITCH, true, BHT>), grid, dim3(256), lds, st, s, d, P, dbg, ntx, ntyt);
