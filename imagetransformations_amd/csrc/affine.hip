@@ -1298,6 +1298,28 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
     const int ntyt = (d.h + BHT - 1) / BHT;
     if (bwt > PITCH || bht > MAXROWS || bw > PITCH || (int64_t)ntx * ntyt * ntx >= ((int64_t)1 << 32))
         return BILINEAR_TALL_NOT_TAKEN;
+    // batches: every tile loops over `fpb` frames per workgroup with the per-pixel geometry held in
+    // registers (affine_mf.inc); single frames and the fp32 side output keep the per-frame kernels
+    const bool want_f32 = dbg.p != nullptr;
+    const char* fpb_env = getenv("IMGXF_AFFINE_FPB");
+    const int fpb = fpb_env ? atoi(fpb_env) : 16;
+    const int afpb = fpb < 0 ? -fpb : fpb;
+    const bool mf = BHT == MF_TILE_H && !want_f32 && afpb >= 2 && d.n >= 2 && bht <= 64 &&
+                    (int64_t)d.h * d.rs < ((int64_t)1 << 32);
+    // LDS-DMA staging of packed rows needs 16-byte aligned source rows and a box of <= 52 x 52 pixels; it
+    // also takes the border tiles (no list pass)
+    const int nch = (bwt * 3 + 15 + 15) / 16;                  // 16-byte chunks per packed box row (any alignment of its start)
+    const bool dma = mf && getenv("IMGXF_AFFINE_NO_DMA") == nullptr && bht <= 52 && bwt <= 52 && 52 * nch <= 768 &&
+                     ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 15) == 0 && s.w * 3 >= 16 &&
+                     (int64_t)s.h * s.rs < ((int64_t)1 << 32);
+    if (dma) {
+        const dim3 grid((unsigned)(ntx * ntyt), (unsigned)((d.n + afpb - 1) / afpb));
+        // RGBX pitch 56: fewest bank conflicts of the multiples of 4 (simulated for 30 deg / 1.5x: 4.0 vs 5.8 LDS cycles per gather read at 52)
+        const size_t lds = (size_t)52 * 56 * 4 + 3 * ((size_t)52 * nch * 16 + 64);
+        if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch);
+        else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch);
+        return launch_status();
+    }
     // the kernel's interior test (bilinear_tile<.., BHT, true>) with the same integers
     TileList list;
     list.n = 0;
@@ -1318,34 +1340,15 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
             }
         }
     if (list.n > BILINEAR_LIST_MAX) return BILINEAR_TALL_NOT_TAKEN;
-    const bool want_f32 = dbg.p != nullptr;
-    // batches: the interior tiles loop over `fpb` frames per workgroup with the per-pixel geometry
-    // held in registers (affine_mf.inc); single frames and the fp32 side output keep the per-frame kernel
-    const char* fpb_env = getenv("IMGXF_AFFINE_FPB");
-    const int fpb = fpb_env ? atoi(fpb_env) : 8;
-    const int afpb = fpb < 0 ? -fpb : fpb;
-    const bool mf = BHT == MF_TILE_H && !want_f32 && afpb >= 2 && d.n >= 2 && bht <= 64 &&
-                    (int64_t)d.h * d.rs < ((int64_t)1 << 32);
     if (list.n < ntx * ntyt && mf) {
         const dim3 grid((unsigned)(ntx * ntyt), (unsigned)((d.n + afpb - 1) / afpb));
-        // LDS-DMA staging of packed rows needs 16-byte aligned source rows and a box of <= 52 x 52 pixels
-        const int nch = (bwt * 3 + 15 + 15) / 16;              // 16-byte chunks per packed box row (any alignment of its start)
-        const bool dma = getenv("IMGXF_AFFINE_NO_DMA") == nullptr && bht <= 52 && bwt <= 52 && 52 * nch <= 768 &&
-                         ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 15) == 0 && s.w * 3 >= 16 &&
-                         (int64_t)s.h * s.rs < ((int64_t)1 << 32);
-        if (dma) {
-            const size_t lds = (size_t)52 * 56 * 4 + 2 * ((size_t)52 * nch * 16 + 64);   // RGBX pitch 56: fewest bank conflicts of the multiples of 4 (simulated: 4.0 vs 5.8 LDS cycles per gather read at pitch 52)
-            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch);
-            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch);
+        const size_t lds = (size_t)2 * PITCH * (bht <= 52 ? 52 : 64) * 4 + 16;     // all 4 * NBR rows are written
+        if (bht <= 52) {
+            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
+            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
         } else {
-            const size_t lds = (size_t)2 * PITCH * (bht <= 52 ? 52 : 64) * 4 + 16;     // all 4 * NBR rows are written
-            if (bht <= 52) {
-                if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
-                else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
-            } else {
-                if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
-                else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
-            }
+            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
+            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
         }
         IMGXF_CHECK(launch_status());
     } else if (list.n < ntx * ntyt) {                // at least one interior tile

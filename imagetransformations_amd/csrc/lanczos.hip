@@ -542,7 +542,7 @@ IMGXF_API int imgxf_resample_plan_create_window(imgxf_lanczos_plan** plan, int i
                                                 int wx, int wy, int ww, int wh) {
     if (!plan) return IMGXF_ERR_NULL;
     *plan = nullptr;
-    if (in_h_full < 1 || in_w < 1 || out_h_full < 1 || out_w_full < 1 || max_frames < 1) return IMGXF_ERR_ARG;
+    if (in_h_full < 1 || in_w < 1 || out_h_full < 1 || out_w_full < 1 || max_frames < 0) return IMGXF_ERR_ARG;
     if (filter < IMGXF_RESAMPLE_LANCZOS || filter > IMGXF_RESAMPLE_HAMMING) return IMGXF_ERR_ARG;
     if (c != 1 && c != 3 && c != 4) return IMGXF_ERR_UNSUPPORTED;
     if (wx < 0 || wy < 0 || ww < 1 || wh < 1 || wx + ww > out_w_full || wy + wh > out_h_full) return IMGXF_ERR_ARG;
@@ -632,7 +632,7 @@ IMGXF_API int imgxf_resample_plan_create_window(imgxf_lanczos_plan** plan, int i
             }
         }
     }
-    if (rc == IMGXF_OK && p->need_h && p->need_v) {
+    if (rc == IMGXF_OK && p->need_h && p->need_v && max_frames > 0) {     // max_frames == 0: workspace-only plan
         hipError_t e = hipMalloc((void**)&p->d_tmp, (size_t)max_frames * p->rh * out_w * c);
         if (e != hipSuccess) rc = (int)e;
     }
@@ -658,15 +658,46 @@ IMGXF_API int imgxf_lanczos_plan_destroy(imgxf_lanczos_plan* p) {
     return IMGXF_OK;
 }
 
+// Bytes of the H -> V intermediate for n frames (0 when the plan runs a single pass)
+static size_t resample_tmp_bytes(const imgxf_lanczos_plan* p, int n) {
+    return (p->need_h && p->need_v) ? (size_t)n * p->rh * p->out_w * p->c : 0;
+}
+
+IMGXF_API int imgxf_resample_workspace_bytes(const imgxf_lanczos_plan* p, int n, size_t* bytes) {
+    if (!p || !bytes) return IMGXF_ERR_NULL;
+    if (n < 0) return IMGXF_ERR_ARG;
+    *bytes = resample_tmp_bytes(p, n);
+    return IMGXF_OK;
+}
+
+static int run_resample(const imgxf_lanczos_plan* p, const imgxf_view* src, const imgxf_view* dst,
+                        uint8_t* tmp, void* stream);
+
 IMGXF_API int imgxf_resize_lanczos_u8(const imgxf_lanczos_plan* p, const imgxf_view* src,
                                       const imgxf_view* dst, void* stream) {
-    if (!p) return IMGXF_ERR_NULL;
+    if (!p || !src) return IMGXF_ERR_NULL;
+    if (src->n > p->max_frames) return IMGXF_ERR_WORKSPACE;
+    return run_resample(p, src, dst, p->d_tmp, stream);
+}
+
+// Same resample with the intermediate in a caller-provided, stream-ordered workspace: the plan
+// holds only immutable coefficient tables, so one plan serves any number of streams (and any
+// batch size) concurrently and nothing is allocated or freed at call time (graph-capture safe).
+IMGXF_API int imgxf_resample_ws_u8(const imgxf_lanczos_plan* p, const imgxf_view* src, const imgxf_view* dst,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p || !src) return IMGXF_ERR_NULL;
+    const size_t need = resample_tmp_bytes(p, src->n);
+    if (need && (!workspace || workspace_bytes < need)) return IMGXF_ERR_WORKSPACE;
+    return run_resample(p, src, dst, (uint8_t*)workspace, stream);
+}
+
+static int run_resample(const imgxf_lanczos_plan* p, const imgxf_view* src, const imgxf_view* dst,
+                        uint8_t* tmp, void* stream) {
     IMGXF_CHECK(check_view(src));
     IMGXF_CHECK(check_view(dst));
     if (src->n != dst->n || src->c != p->c || dst->c != p->c) return IMGXF_ERR_SHAPE;
     if (src->h != p->in_h || src->w != p->in_w || dst->h != p->out_h || dst->w != p->out_w)
         return IMGXF_ERR_SHAPE;
-    if (src->n > p->max_frames) return IMGXF_ERR_WORKSPACE;
     if (src->n == 0) return IMGXF_OK;
     hipStream_t st = (hipStream_t)stream;
     const View s = make_view(src), d = make_view(dst);
@@ -689,7 +720,8 @@ IMGXF_API int imgxf_resize_lanczos_u8(const imgxf_lanczos_plan* p, const imgxf_v
     if (p->need_h) {
         View sub = s;                                  // the source rows the window's vertical taps touch
         sub.p = s.p + (int64_t)p->ry0 * s.rs; sub.h = p->rh;
-        mid.p = p->d_tmp; mid.n = s.n; mid.h = p->rh; mid.w = p->out_w; mid.c = p->c;
+        if (!tmp) return IMGXF_ERR_WORKSPACE;
+        mid.p = tmp; mid.n = s.n; mid.h = p->rh; mid.w = p->out_w; mid.c = p->c;
         mid.rs = (int64_t)p->out_w * p->c; mid.fs = mid.rs * p->rh;
         IMGXF_CHECK(run_h(sub, mid));
     }

@@ -22,8 +22,14 @@ RESAMPLE_LANCZOS, RESAMPLE_BILINEAR, RESAMPLE_BICUBIC, RESAMPLE_BOX, RESAMPLE_HA
 REFLECT_101, REFLECT = F.BORDER_REFLECT_101, F.BORDER_REFLECT
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _launch(t: torch.Tensor, name: str, *args) -> None:
+    """Call a libimgxf entry point on `t`'s device and that device's current torch stream.
+
+    The device comes from the tensor, not from torch's current device: a tensor on cuda:k while
+    cuda:0 is current (sharding.map_frames on another rank's device, a torchrun rank that skipped
+    set_device) must not have its kernel enqueued on device 0 with device-k pointers."""
+    with torch.cuda.device(t.device):
+        F.call(name, *args, torch.cuda.current_stream(t.device).cuda_stream)
 
 
 def _check_u8(t: torch.Tensor, name: str = "image") -> torch.Tensor:
@@ -74,11 +80,11 @@ def gaussian_blur(t: torch.Tensor, ksize: int, sigma: float, return_f32: bool = 
     if fixed_point:
         if return_f32:
             raise ValueError("the fixed-point path has no fp32 intermediate")
-        F.call("imgxf_gaussian_cv_fixed_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), int(ksize), float(sigma), _stream())
+        _launch(t, "imgxf_gaussian_cv_fixed_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), int(ksize), float(sigma))
         return out
     f32 = torch.empty(t.shape, dtype=torch.float32, device=t.device) if return_f32 else None
-    F.call("imgxf_gaussian_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), int(ksize), float(sigma),
-           F.vp(F.view_of(f32)) if return_f32 else None, _stream())
+    _launch(t, "imgxf_gaussian_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), int(ksize), float(sigma),
+           F.vp(F.view_of(f32)) if return_f32 else None)
     return (out, f32) if return_f32 else out
 
 
@@ -87,8 +93,8 @@ def sepconv(t: torch.Tensor, kx: Sequence[float], ky: Sequence[float], border: i
     t = _check_u8(t)
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
     f32 = torch.empty(t.shape, dtype=torch.float32, device=t.device) if return_f32 else None
-    F.call("imgxf_sepconv_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(kx), len(kx),
-           F.f32_array(ky), len(ky), border, F.vp(F.view_of(f32)) if return_f32 else None, _stream())
+    _launch(t, "imgxf_sepconv_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(kx), len(kx),
+           F.f32_array(ky), len(ky), border, F.vp(F.view_of(f32)) if return_f32 else None)
     return (out, f32) if return_f32 else out
 
 
@@ -100,7 +106,7 @@ def sepconv_fixed(t: torch.Tensor, kx: Sequence[int], ky: Sequence[int], border:
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
     ax = (ctypes.c_uint16 * len(kx))(*[int(v) for v in kx])
     ay = (ctypes.c_uint16 * len(ky))(*[int(v) for v in ky])
-    F.call("imgxf_sepconv_fixed_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), ax, len(kx), ay, len(ky), border, _stream())
+    _launch(t, "imgxf_sepconv_fixed_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), ax, len(kx), ay, len(ky), border)
     return out
 
 
@@ -114,8 +120,8 @@ def conv2d(t: torch.Tensor, kernel, border: int = REFLECT_101) -> torch.Tensor:
         raise ValueError("kernel must be rectangular")
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
     flat = [v for r in rows for v in r]
-    F.call("imgxf_conv2d_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(flat), kh, kw,
-           border, _stream())
+    _launch(t, "imgxf_conv2d_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(flat), kh, kw,
+           border)
     return out
 
 
@@ -124,7 +130,7 @@ def sobel(gray: torch.Tensor, variant: int = F.SOBEL_X_WRAP) -> torch.Tensor:
     """scipy.ndimage.sobel(gray_u8) — transformation.py:339 (variant 0), or |G| (variant 2)."""
     gray = _check_u8(gray, "gray")
     out = torch.empty_like(gray, memory_format=torch.contiguous_format)
-    F.call("imgxf_sobel_u8", F.vp(_gray_view(gray)), F.vp(_gray_view(out)), int(variant), _stream())
+    _launch(gray, "imgxf_sobel_u8", F.vp(_gray_view(gray)), F.vp(_gray_view(out)), int(variant))
     return out
 
 
@@ -132,7 +138,7 @@ def rgb_sobel_magnitude(rgb: torch.Tensor) -> torch.Tensor:
     """Fused RGB -> L -> (Gx,Gy) -> |G| -> uint8 (benchmark configs[2])."""
     rgb = _check_u8(rgb)
     out = _gray_like(rgb)
-    F.call("imgxf_rgb_sobel_mag_u8", F.vp(F.view_of(rgb)), F.vp(_gray_view(out)), _stream())
+    _launch(rgb, "imgxf_rgb_sobel_mag_u8", F.vp(F.view_of(rgb)), F.vp(_gray_view(out)))
     return out
 
 
@@ -140,7 +146,7 @@ def rgb_sobel(rgb: torch.Tensor, variant: int = F.SOBEL_X_WRAP) -> torch.Tensor:
     """sobel(rgb2l(rgb), variant) without materialising L (transformation.py:336-339)."""
     rgb = _check_u8(rgb)
     out = _gray_like(rgb)
-    F.call("imgxf_rgb_sobel_u8", F.vp(F.view_of(rgb)), F.vp(_gray_view(out)), int(variant), _stream())
+    _launch(rgb, "imgxf_rgb_sobel_u8", F.vp(F.view_of(rgb)), F.vp(_gray_view(out)), int(variant))
     return out
 
 
@@ -174,14 +180,14 @@ def affine(t: torch.Tensor, matrix: Sequence[float], out_size: tuple[int, int] |
     fill = _fill_bytes(fillcolor, c)
     if resample == NEAREST and m[1] == 0.0 and m[3] == 0.0:
         ws = torch.empty(ow + oh + 2, dtype=torch.int32, device=t.device)
-        F.call("imgxf_affine_scale_nearest_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f64_array(m),
-               fill, ws.data_ptr(), ws.numel() * 4, _stream())
+        _launch(t, "imgxf_affine_scale_nearest_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f64_array(m),
+               fill, ws.data_ptr(), ws.numel() * 4)
         return out
     f32 = None
     if return_f32:
         f32 = torch.empty(out.shape, dtype=torch.float32, device=t.device)
-    F.call("imgxf_affine_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f64_array(m), int(resample),
-           fill, 1 if precise else 0, F.vp(F.view_of(f32)) if return_f32 else None, _stream())
+    _launch(t, "imgxf_affine_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f64_array(m), int(resample),
+           fill, 1 if precise else 0, F.vp(F.view_of(f32)) if return_f32 else None)
     return (out, f32) if return_f32 else out
 
 
@@ -219,7 +225,7 @@ def flip(t: torch.Tensor, top_bottom: bool = False) -> torch.Tensor:
     """Image.transpose(FLIP_LEFT_RIGHT) (default) / FLIP_TOP_BOTTOM."""
     t = _check_u8(t)
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_flip_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), 1 if top_bottom else 0, _stream())
+    _launch(t, "imgxf_flip_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), 1 if top_bottom else 0)
     return out
 
 
@@ -236,8 +242,8 @@ def perspective(t: torch.Tensor, coeffs) -> torch.Tensor:
     if len(flat) != 8 * (len(rows) if rows is not None else 1):
         raise ValueError("perspective coefficients come in rows of eight")
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_perspective_bilinear_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(flat),
-           1 if rows is not None else 0, _stream())
+    _launch(t, "imgxf_perspective_bilinear_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(flat),
+           1 if rows is not None else 0)
     return out
 
 
@@ -248,7 +254,7 @@ def rot90(t: torch.Tensor, quarter_turns_ccw: int) -> torch.Tensor:
     if k == 0:
         return t.clone()
     out = _like(t, w, h) if k != 2 else torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_rot90_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), k, _stream())
+    _launch(t, "imgxf_rot90_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), k)
     return out
 
 
@@ -269,34 +275,49 @@ def rotate(t: torch.Tensor, angle: float, resample: int = NEAREST, fillcolor=Non
 
 # ---------------------------------------------------------------- a3 Lanczos resize
 class _PlanCache:
+    """Resample plans hold only immutable device coefficient tables (created with max_frames = 0);
+    the H -> V intermediate is a per-call torch tensor, i.e. stream-ordered workspace.  One cached
+    plan therefore serves every stream and batch size, is never destroyed on growth (a captured HIP
+    graph keeps valid pointers) and a cached plan's call neither allocates nor synchronises outside
+    torch's allocator.  Plan CREATION (first use of a geometry) uploads tables synchronously and
+    must happen outside stream capture."""
+
     def __init__(self):
         self._plans: dict = {}
 
-    def get(self, in_h, in_w, out_h, out_w, c, n, device_index, resample=1, window=None):
+    def get(self, in_h, in_w, out_h, out_w, c, device_index, resample=1, window=None):
         key = (in_h, in_w, out_h, out_w, c, device_index, resample, window)
-        ent = self._plans.get(key)
-        if ent is not None and ent[1] >= n:
-            return ent[0]
-        if ent is not None:
-            F.call("imgxf_lanczos_plan_destroy", ent[0])
+        handle = self._plans.get(key)
+        if handle is not None:
+            return handle
         import ctypes
         handle = ctypes.c_void_p()
         with torch.cuda.device(device_index):
             if window is None:
-                F.call("imgxf_resample_plan_create", ctypes.byref(handle), in_h, in_w, out_h, out_w, c, n, resample)
+                F.call("imgxf_resample_plan_create", ctypes.byref(handle), in_h, in_w, out_h, out_w, c, 0, resample)
             else:
-                F.call("imgxf_resample_plan_create_window", ctypes.byref(handle), in_h, in_w, out_h, out_w, c, n,
+                F.call("imgxf_resample_plan_create_window", ctypes.byref(handle), in_h, in_w, out_h, out_w, c, 0,
                        resample, *window)
-        self._plans[key] = (handle, n)
+        self._plans[key] = handle
         return handle
 
     def clear(self):
-        for handle, _ in self._plans.values():
+        for handle in self._plans.values():
             F.lib.imgxf_lanczos_plan_destroy(handle)
         self._plans.clear()
 
 
 _plans = _PlanCache()
+
+
+def _run_plan(plan, t: torch.Tensor, out: torch.Tensor, n: int) -> None:
+    import ctypes
+    nbytes = ctypes.c_size_t()
+    F.call("imgxf_resample_workspace_bytes", plan, n, ctypes.byref(nbytes))
+    ws = torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8, device=t.device)
+    with torch.cuda.device(t.device):
+        F.call("imgxf_resample_ws_u8", plan, F.vp(F.view_of(t)), F.vp(F.view_of(out)), ws.data_ptr(), int(nbytes.value),
+               torch.cuda.current_stream(t.device).cuda_stream)
 
 
 def resize_lanczos(t: torch.Tensor, size: tuple[int, int]) -> torch.Tensor:
@@ -326,8 +347,8 @@ def resize(t: torch.Tensor, size: tuple[int, int], resample: int = RESAMPLE_BICU
             raise ValueError(f"out must be a uint8 tensor of shape {tuple(want)} on {t.device}")
     if n == 0:
         return out
-    plan = _plans.get(h, w, nh, nw, c, n, t.device.index or 0, int(resample))
-    F.call("imgxf_resize_lanczos_u8", plan, F.vp(F.view_of(t)), F.vp(F.view_of(out)), _stream())
+    plan = _plans.get(h, w, nh, nw, c, t.device.index or 0, int(resample))
+    _run_plan(plan, t, out, n)
     return out
 
 
@@ -348,8 +369,8 @@ def resize_crop(t: torch.Tensor, size: tuple[int, int], box: tuple[int, int, int
     out = _like(t, b - tp, r - l)
     if n == 0:
         return out
-    plan = _plans.get(h, w, nh, nw, c, n, t.device.index or 0, int(resample), (l, tp, r - l, b - tp))
-    F.call("imgxf_resize_lanczos_u8", plan, F.vp(F.view_of(t)), F.vp(F.view_of(out)), _stream())
+    plan = _plans.get(h, w, nh, nw, c, t.device.index or 0, int(resample), (l, tp, r - l, b - tp))
+    _run_plan(plan, t, out, n)
     return out
 
 
@@ -358,13 +379,13 @@ def new(like: torch.Tensor, h: int, w: int, color=(0, 0, 0)) -> torch.Tensor:
     """Image.new(mode, (w,h), color) for a batch shaped like `like`."""
     _, _, c = _hwc(like)
     out = _like(like, h, w)
-    F.call("imgxf_fill_u8", F.vp(F.view_of(out)), _fill_bytes(color, c), _stream())
+    _launch(out, "imgxf_fill_u8", F.vp(F.view_of(out)), _fill_bytes(color, c))
     return out
 
 
 def copy_rect(src: torch.Tensor, dst: torch.Tensor, sx: int, sy: int, dx: int, dy: int, rw: int, rh: int) -> None:
     src = _check_u8(src, "src")
-    F.call("imgxf_copy_rect_u8", F.vp(F.view_of(src)), F.vp(F.view_of(dst)), sx, sy, dx, dy, rw, rh, _stream())
+    _launch(src, "imgxf_copy_rect_u8", F.vp(F.view_of(src)), F.vp(F.view_of(dst)), sx, sy, dx, dy, rw, rh)
 
 
 def crop(t: torch.Tensor, box: tuple[int, int, int, int]) -> torch.Tensor:
@@ -382,7 +403,7 @@ def rgb2l(t: torch.Tensor) -> torch.Tensor:
     if t.dim() < 3:
         raise ValueError("rgb2l expects an interleaved RGB(A) image")
     out = _gray_like(t)
-    F.call("imgxf_rgb2l_u8", F.vp(F.view_of(t)), F.vp(_gray_view(out)), _stream())
+    _launch(t, "imgxf_rgb2l_u8", F.vp(F.view_of(t)), F.vp(_gray_view(out)))
     return out
 
 
@@ -390,7 +411,7 @@ def scale_abs(t: torch.Tensor, alpha: float, beta: float = 0.0) -> torch.Tensor:
     """cv2.convertScaleAbs(img, alpha=alpha, beta=beta) — transformation.py:207."""
     t = _check_u8(t)
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_scale_abs_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(alpha), float(beta), _stream())
+    _launch(t, "imgxf_scale_abs_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(alpha), float(beta))
     return out
 
 
@@ -408,10 +429,10 @@ def blend(im1, im2, alpha: float, like: torch.Tensor | None = None) -> torch.Ten
     if t1 is not None and t2 is not None and t1.shape != t2.shape:
         raise ValueError("images do not match")   # Pillow's message
     out = torch.empty_like(ref, memory_format=torch.contiguous_format)
-    F.call("imgxf_blend_u8",
+    _launch(ref, "imgxf_blend_u8",
            F.vp(F.view_of(t1)) if t1 is not None else None, None if t1 is not None else _fill_bytes(im1, c),
            F.vp(F.view_of(t2)) if t2 is not None else None, None if t2 is not None else _fill_bytes(im2, c),
-           F.vp(F.view_of(out)), float(alpha), _stream())
+           F.vp(F.view_of(out)), float(alpha))
     return out
 
 
@@ -427,8 +448,8 @@ def box_blur(t: torch.Tensor, radius: float, passes: int = 1) -> torch.Tensor:
         raise ValueError("radius must be >= 0")        # Pillow's message
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
     ws = torch.empty_like(out)
-    F.call("imgxf_box_blur_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(radius), float(radius), int(passes),
-           ws.data_ptr(), ws.numel(), _stream())
+    _launch(t, "imgxf_box_blur_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(radius), float(radius), int(passes),
+           ws.data_ptr(), ws.numel())
     return out
 
 
@@ -437,8 +458,8 @@ def gaussian_blur_pil(t: torch.Tensor, radius: float) -> torch.Tensor:
     t = _check_u8(t)
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
     ws = torch.empty_like(out)
-    F.call("imgxf_gaussian_blur_pil_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(radius),
-           ws.data_ptr(), ws.numel(), _stream())
+    _launch(t, "imgxf_gaussian_blur_pil_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(radius),
+           ws.data_ptr(), ws.numel())
     return out
 
 
@@ -451,8 +472,8 @@ def filter3x3(t: torch.Tensor, kernel9: Sequence[float], scale: float, offset: f
     if len(kernel9) != 9:
         raise ValueError("not enough coefficients in kernel")      # Pillow's message
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_filter3x3_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(kernel9), float(scale),
-           float(offset), _stream())
+    _launch(t, "imgxf_filter3x3_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.f32_array(kernel9), float(scale),
+           float(offset))
     return out
 
 
@@ -466,7 +487,7 @@ def enhance_color(t: torch.Tensor, factor: float) -> torch.Tensor:
     """ImageEnhance.Color(img).enhance(factor) — cifar_image_transformations.py:102-106."""
     t = _check_u8(t)
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_enhance_color_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(factor), _stream())
+    _launch(t, "imgxf_enhance_color_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(factor))
     return out
 
 
@@ -476,8 +497,8 @@ def enhance_contrast(t: torch.Tensor, factor: float) -> torch.Tensor:
     n = t.shape[0] if t.dim() == 4 else 1
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
     sums = torch.empty(max(n, 1), dtype=torch.int64, device=t.device)
-    F.call("imgxf_enhance_contrast_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(factor),
-           sums.data_ptr(), _stream())
+    _launch(t, "imgxf_enhance_contrast_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(factor),
+           sums.data_ptr())
     return out
 
 
@@ -488,7 +509,7 @@ def add_noise(t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
         raise ValueError("noise must be a float32 device tensor shaped like the image")
     noise = noise.contiguous()
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_add_noise_u8", F.vp(F.view_of(t)), F.vp(F.view_of(noise)), F.vp(F.view_of(out)), _stream())
+    _launch(t, "imgxf_add_noise_u8", F.vp(F.view_of(t)), F.vp(F.view_of(noise)), F.vp(F.view_of(out)))
     return out
 
 
@@ -499,7 +520,7 @@ def add_noise_f64(t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
         raise ValueError("noise must be a float64 device tensor shaped like the image")
     noise = noise.contiguous()
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_add_noise_f64_u8", F.vp(F.view_of(t)), F.vp(F.view_of(noise)), F.vp(F.view_of(out)), _stream())
+    _launch(t, "imgxf_add_noise_f64_u8", F.vp(F.view_of(t)), F.vp(F.view_of(noise)), F.vp(F.view_of(out)))
     return out
 
 
@@ -509,7 +530,7 @@ def shot_noise_finish(counts: torch.Tensor, lam: float) -> torch.Tensor:
         raise ValueError("counts must be a float64 device tensor")
     counts = counts.contiguous()
     out = torch.empty(counts.shape, dtype=torch.uint8, device=counts.device)
-    F.call("imgxf_shot_noise_u8", F.vp(F.view_of(counts)), float(lam), F.vp(F.view_of(out)), _stream())
+    _launch(counts, "imgxf_shot_noise_u8", F.vp(F.view_of(counts)), float(lam), F.vp(F.view_of(out)))
     return out
 
 
@@ -520,8 +541,8 @@ def impulse_noise(t: torch.Tensor, mask: torch.Tensor, lo: float, hi: float) -> 
         raise ValueError("mask must be a float64 device tensor shaped like the image without channels")
     mask = mask.contiguous().unsqueeze(-1)
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_impulse_noise_u8", F.vp(F.view_of(t)), F.vp(F.view_of(mask)), float(lo), float(hi),
-           F.vp(F.view_of(out)), _stream())
+    _launch(t, "imgxf_impulse_noise_u8", F.vp(F.view_of(t)), F.vp(F.view_of(mask)), float(lo), float(hi),
+           F.vp(F.view_of(out)))
     return out
 
 
@@ -535,7 +556,7 @@ def lut(t: torch.Tensor, table) -> torch.Tensor:
     if len(tab) != 256 * c:
         raise ValueError(f"lookup table needs 256 or {256 * c} entries, got {len(tab)}")
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_lut_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.u8_array(tab, len(tab)), _stream())
+    _launch(t, "imgxf_lut_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.u8_array(tab, len(tab)))
     return out
 
 
@@ -558,7 +579,7 @@ def equalize(t: torch.Tensor) -> torch.Tensor:
     n = t.shape[0] if t.dim() == 4 else 1
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
     ws = torch.empty(max(1, n * c * 256 * 5 // 4 + 1), dtype=torch.int32, device=t.device)
-    F.call("imgxf_equalize_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), ws.data_ptr(), ws.numel() * 4, _stream())
+    _launch(t, "imgxf_equalize_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), ws.data_ptr(), ws.numel() * 4)
     return out
 
 
@@ -566,7 +587,7 @@ def rgb2yuv(t: torch.Tensor) -> torch.Tensor:
     """cv2.cvtColor(img, cv2.COLOR_RGB2YUV) for 8-bit RGB (parity unpinned: OpenCV's integer definition)."""
     t = _check_u8(t)
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_rgb2yuv_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), _stream())
+    _launch(t, "imgxf_rgb2yuv_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)))
     return out
 
 
@@ -574,7 +595,7 @@ def yuv2rgb(t: torch.Tensor) -> torch.Tensor:
     """cv2.cvtColor(img, cv2.COLOR_YUV2RGB) for 8-bit YUV (parity unpinned)."""
     t = _check_u8(t)
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
-    F.call("imgxf_yuv2rgb_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), _stream())
+    _launch(t, "imgxf_yuv2rgb_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)))
     return out
 
 
@@ -585,8 +606,8 @@ def equalize_hist_cv(t: torch.Tensor, channel: int = 0) -> torch.Tensor:
     n = t.shape[0] if t.dim() == 4 else 1
     out = torch.empty_like(t, memory_format=torch.contiguous_format)
     ws = torch.empty(max(1, n * c * 256 * 5 // 4 + 1), dtype=torch.int32, device=t.device)
-    F.call("imgxf_equalize_hist_cv_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), int(channel), ws.data_ptr(),
-           ws.numel() * 4, _stream())
+    _launch(t, "imgxf_equalize_hist_cv_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), int(channel), ws.data_ptr(),
+           ws.numel() * 4)
     return out
 
 
@@ -596,7 +617,7 @@ def channel_histogram(t: torch.Tensor) -> torch.Tensor:
     h, w, c = _hwc(t)
     n = t.shape[0] if t.dim() == 4 else 1
     hist = torch.empty((n, c, 256), dtype=torch.int32, device=t.device)
-    F.call("imgxf_channel_histogram_u8", F.vp(F.view_of(t)), hist.data_ptr(), _stream())
+    _launch(t, "imgxf_channel_histogram_u8", F.vp(F.view_of(t)), hist.data_ptr())
     return hist
 
 
@@ -621,7 +642,7 @@ def permute_channels(t: torch.Tensor, perm: Sequence[int]) -> torch.Tensor:
     """cv2.cvtColor channel shuffles: out[..., j] = t[..., perm[j]]."""
     t = _check_u8(t)
     out = _like(t, c=len(perm))
-    F.call("imgxf_permute_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.i32_array(perm), _stream())
+    _launch(t, "imgxf_permute_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), F.i32_array(perm))
     return out
 
 
@@ -629,8 +650,8 @@ def composite(im1: torch.Tensor, im2: torch.Tensor, mask: torch.Tensor) -> torch
     """Image.composite(im1, im2, mask) for a 0/255 single-channel mask."""
     im1, im2, mask = _check_u8(im1), _check_u8(im2), _check_u8(mask, "mask")
     out = torch.empty_like(im1, memory_format=torch.contiguous_format)
-    F.call("imgxf_composite_u8", F.vp(F.view_of(im1)), F.vp(F.view_of(im2)), F.vp(_gray_view(mask)),
-           F.vp(F.view_of(out)), _stream())
+    _launch(im1, "imgxf_composite_u8", F.vp(F.view_of(im1)), F.vp(F.view_of(im2)), F.vp(_gray_view(mask)),
+           F.vp(F.view_of(out)))
     return out
 
 
@@ -639,8 +660,8 @@ def composite_const(im1: torch.Tensor, colour, mask: torch.Tensor) -> torch.Tens
     im1, mask = _check_u8(im1), _check_u8(mask, "mask")
     c = _hwc(im1)[2]
     out = torch.empty_like(im1, memory_format=torch.contiguous_format)
-    F.call("imgxf_composite_const_u8", F.vp(F.view_of(im1)), _fill_bytes(colour, c), F.vp(_gray_view(mask)),
-           F.vp(F.view_of(out)), _stream())
+    _launch(im1, "imgxf_composite_const_u8", F.vp(F.view_of(im1)), _fill_bytes(colour, c), F.vp(_gray_view(mask)),
+           F.vp(F.view_of(out)))
     return out
 
 
@@ -653,9 +674,9 @@ def percentile_mask(gray: torch.Tensor, q: float, return_threshold: bool = False
     thr = torch.empty(n, dtype=torch.float64, device=gray.device)
     out = torch.empty_like(gray, memory_format=torch.contiguous_format)
     gv = _gray_view(gray)
-    F.call("imgxf_histogram_u8", F.vp(gv), hist.data_ptr(), _stream())
-    F.call("imgxf_percentile_mask_u8", F.vp(gv), hist.data_ptr(), float(q), F.vp(_gray_view(out)),
-           thr.data_ptr(), _stream())
+    _launch(gray, "imgxf_histogram_u8", F.vp(gv), hist.data_ptr())
+    _launch(out, "imgxf_percentile_mask_u8", F.vp(gv), hist.data_ptr(), float(q), F.vp(_gray_view(out)),
+           thr.data_ptr())
     return (out, thr) if return_threshold else out
 
 
@@ -663,5 +684,5 @@ def dilate_cross(mask: torch.Tensor, iterations: int) -> torch.Tensor:
     """scipy.ndimage.binary_dilation(mask, iterations=iterations) on 0/255 masks."""
     mask = _check_u8(mask, "mask")
     out = torch.empty_like(mask, memory_format=torch.contiguous_format)
-    F.call("imgxf_dilate_cross_u8", F.vp(_gray_view(mask)), F.vp(_gray_view(out)), int(iterations), _stream())
+    _launch(mask, "imgxf_dilate_cross_u8", F.vp(_gray_view(mask)), F.vp(_gray_view(out)), int(iterations))
     return out

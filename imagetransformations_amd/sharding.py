@@ -84,13 +84,99 @@ def gather_frames(local: torch.Tensor, n_frames: int, root: int = 0, group=None)
     return out
 
 
+def _on(device: torch.device):
+    """Make `device` the current device for the enclosed launches (a no-op for host tensors)."""
+    import contextlib
+    return torch.cuda.device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
+
+
 def map_frames(fn: Callable[[torch.Tensor], torch.Tensor], frames: Optional[torch.Tensor], n_frames: int,
                frame_shape: Sequence[int], device: torch.device, root: int = 0, group=None):
     """scatter -> fn(local block) -> gather.  `fn` is any per-batch op from `ops` (or a
-    composition); it runs on each rank's block with no communication."""
-    local = scatter_frames(frames, n_frames, frame_shape, device, root, group)
-    out = fn(local) if local.shape[0] > 0 else local
-    return gather_frames(out, n_frames, root, group)
+    composition); it runs on each rank's block with no communication.  `device` is made current
+    for the whole call, so a rank that never called set_device still allocates and launches there."""
+    with _on(device):
+        local = scatter_frames(frames, n_frames, frame_shape, device, root, group)
+        out = fn(local) if local.shape[0] > 0 else local
+        return gather_frames(out, n_frames, root, group)
+
+
+def map_frames_pipelined(fn: Callable[[torch.Tensor], torch.Tensor], frames: Optional[torch.Tensor], n_frames: int,
+                         frame_shape: Sequence[int], device: torch.device, chunk: int = 8, root: int = 0, group=None):
+    """map_frames as a three-stage pipeline over chunks of `chunk` frames:
+
+        step s:   transfers { input chunk s  root -> peers,  output chunk s-2  peers -> root }
+                  ||  fn(chunk s-1) on every rank
+
+    The transfers of one step are ONE grouped batch of point-to-point operations (RCCL progresses the
+    sends and receives of a group concurrently, each root<->peer pair on its own xGMI link), issued
+    before the step's compute and waited for after it, so a rank computes chunk s-1 while chunk s
+    arrives and the result of chunk s-2 leaves.  `fn` must map [k, *frame_shape] -> [k, *out_shape]
+    frame by frame (any `ops` function).  Returns the gathered result on the root, None elsewhere;
+    equal to map_frames for every chunk size."""
+    rank, world = _world(group)
+    if chunk < 1:
+        raise ValueError("chunk >= 1 required")
+    with _on(device):
+        if world == 1:
+            return fn(frames) if n_frames > 0 else frames
+        start, stop = shard_range(n_frames, world, rank)
+        mine = stop - start
+        counts = shard_counts(n_frames, world)
+        nsteps = (max(counts) + chunk - 1) // chunk
+
+        def piece(r: int, k: int) -> tuple[int, int]:
+            """frames [a, b) of rank r's block that form its chunk k (empty when k is out of range)"""
+            a = min(k * chunk, counts[r])
+            return a, min(a + chunk, counts[r])
+
+        is_root = rank == root
+        local_in = frames[start:stop] if is_root else torch.empty((mine, *frame_shape), dtype=torch.uint8, device=device)
+        local_out = None            # peers: results of the own block, allocated once fn's output shape is known
+        result = None               # root: the gathered batch
+
+        for s in range(nsteps + 2):
+            ops = []
+            # ---- transfers of step s (posted first, waited for after the compute)
+            if is_root:
+                for peer in range(world):
+                    if peer == root:
+                        continue
+                    ps, _ = shard_range(n_frames, world, peer)
+                    a, b = piece(peer, s)
+                    if b > a:
+                        ops.append(dist.P2POp(dist.isend, frames[ps + a:ps + b].contiguous(), peer, group))
+                    a, b = piece(peer, s - 2)
+                    if s >= 2 and b > a:
+                        ops.append(dist.P2POp(dist.irecv, result[ps + a:ps + b], peer, group))
+            else:
+                a, b = piece(rank, s)
+                if b > a:
+                    ops.append(dist.P2POp(dist.irecv, local_in[a:b], root, group))
+                a, b = piece(rank, s - 2)
+                if s >= 2 and b > a:
+                    ops.append(dist.P2POp(dist.isend, local_out[a:b], root, group))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            # ---- compute chunk s-1 (its input arrived with step s-1's transfers)
+            a, b = piece(rank, s - 1)
+            if s >= 1 and b > a:
+                y = fn(local_in[a:b])
+                if is_root:
+                    if result is None:
+                        result = torch.empty((n_frames, *y.shape[1:]), dtype=y.dtype, device=y.device)
+                    result[start + a:start + b].copy_(y)
+                else:
+                    if local_out is None:
+                        local_out = torch.empty((mine, *y.shape[1:]), dtype=y.dtype, device=y.device)
+                    local_out[a:b].copy_(y)
+            if is_root and s == 1 and result is None and n_frames > 0:
+                # an empty root block (root != 0, fewer frames than ranks): the output geometry of the
+                # receives posted from step 2 on comes from one probe frame
+                y = fn(frames[:1])
+                result = torch.empty((n_frames, *y.shape[1:]), dtype=y.dtype, device=y.device)
+            for req in reqs:
+                req.wait()
+        return result if is_root else None
 
 
 def checksum(t: torch.Tensor, group=None) -> int:

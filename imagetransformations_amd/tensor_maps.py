@@ -13,8 +13,10 @@ from . import _ffi as F
 _BRIGHTNESS, _CONTRAST, _NOISE = 0, 1, 2
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _launch(t: torch.Tensor, name: str, *args) -> None:
+    """Enqueue on the tensor's own device and that device's current stream (ops._launch)."""
+    with torch.cuda.device(t.device):
+        F.call(name, *args, torch.cuda.current_stream(t.device).cuda_stream)
 
 
 def _check(t: torch.Tensor) -> torch.Tensor:
@@ -28,8 +30,8 @@ def _check(t: torch.Tensor) -> torch.Tensor:
 def _run(mode: int, x: torch.Tensor, noise, p0: float, p1: float, want_mask: bool):
     out = torch.empty_like(x)
     mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_mask else None
-    F.call("imgxf_f32_map", x.data_ptr(), noise.data_ptr() if noise is not None else None, out.data_ptr(),
-           mask.data_ptr() if mask is not None else None, x.numel(), mode, float(p0), float(p1), _stream())
+    _launch(x, "imgxf_f32_map", x.data_ptr(), noise.data_ptr() if noise is not None else None, out.data_ptr(),
+            mask.data_ptr() if mask is not None else None, x.numel(), mode, float(p0), float(p1))
     return out, mask
 
 
@@ -84,8 +86,8 @@ def to_tensor(frames: torch.Tensor, mean=None, std=None) -> torch.Tensor:
     if mean is not None and (len(mean) != c or len(std) != c):
         raise ValueError(f"mean / std need {c} entries")
     out = torch.empty((n, c, h, w), dtype=torch.float32, device=frames.device)
-    F.call("imgxf_to_tensor_f32", F.vp(v), out.data_ptr(), F.f32_array(mean) if mean is not None else None,
-           F.f32_array(std) if std is not None else None, _stream())
+    _launch(frames, "imgxf_to_tensor_f32", F.vp(v), out.data_ptr(), F.f32_array(mean) if mean is not None else None,
+            F.f32_array(std) if std is not None else None)
     return out if frames.dim() == 4 else out[0]
 
 

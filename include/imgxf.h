@@ -152,6 +152,14 @@ int imgxf_resample_plan_create(imgxf_lanczos_plan** plan, int in_h, int in_w, in
 int imgxf_resample_plan_create_window(imgxf_lanczos_plan** plan, int in_h, int in_w, int out_h,
                                       int out_w, int c, int max_frames, int filter,
                                       int wx, int wy, int ww, int wh);
+/* Stream-safe form: with max_frames == 0 a plan holds only its immutable coefficient tables; the
+ * uint8 H -> V intermediate ([n][rows the window's taps touch][out_w][c] bytes, 0 for single-pass
+ * plans) is a caller-provided, stream-ordered workspace, so one plan may run on any number of
+ * streams and batch sizes at once and the call neither allocates nor frees (graph-capture safe).
+ * Replaces the shared-intermediate contract of imgxf_resize_lanczos_u8 above. */
+int imgxf_resample_workspace_bytes(const imgxf_lanczos_plan* plan, int n, size_t* bytes);
+int imgxf_resample_ws_u8(const imgxf_lanczos_plan* plan, const imgxf_view* src, const imgxf_view* dst,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- a6: elementwise colour maps ------------------------------------------------------*/
 /* Pillow convert('L') transformation.py:336: (19595R+38470G+7471B+0x8000)>>16. src c in {3,4}, dst c==1 */

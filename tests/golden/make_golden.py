@@ -146,6 +146,47 @@ def main():
             for op, prm, out in rows:
                 fh.write(f"{op}\t{h}\t{w}\t{prm!r}\t{hashlib.sha256(np.asarray(out).tobytes()).hexdigest()}\n")
     print(f"wrote {len(meta)} cases")
+    driver_fixture()
+
+
+DRIVER_ORDER = ['scale', 'rotation', 'lighten_darken', 'gaussian_noise', 'translation', 'contrast', 'blur', 'shear']
+
+
+def driver_fixture():
+    """for seed S and a synthetic 48x64 RGB input, the driver loop of
+    /root/reference/transformation.py:113-139 (one `random.choice(grid)` per transform type, two for
+    translation, in the dict's order; file name f"{name}_{type}_{value}_corrupted.jpg") with every
+    transform evaluated by the LIBRARY call the reference makes -> (type, value, file name, sha256).
+    Rows of the cv2-backed types (contrast, blur) carry the float-definition hash and pinned = 0."""
+    import random
+    a = synth(5, 48, 64)
+    img = Image.fromarray(a)
+    with open(os.path.join(HERE, "driver_fixture.tsv"), "w") as fh:
+        fh.write("seed\ttype\tvalue\tfilename\tsha256\tpinned\n")
+        for seed in (1234, 7, 2024):
+            random.seed(seed)
+            np.random.seed(99)
+            for ttype in DRIVER_ORDER:
+                grid = O.grid_values(ttype)
+                pinned = 1
+                if ttype == 'translation':
+                    tx = random.choice(grid); ty = random.choice(grid)
+                    value, fname = (tx, ty), f"img0_{ttype}_{tx}_{ty}_corrupted.jpg"
+                    out = ref_translation(img, tx, ty)
+                else:
+                    v = random.choice(grid)
+                    value, fname = (v,), f"img0_{ttype}_{v}_corrupted.jpg"
+                    if ttype == 'scale': out = ref_scale(img, v)                                        # :173-196
+                    elif ttype == 'rotation': out = img.rotate(-v, fillcolor=(0, 0, 0), expand=False)    # :198-201
+                    elif ttype == 'lighten_darken': out = ImageEnhance.Brightness(img).enhance(1.0 + v)  # :261-269
+                    elif ttype == 'gaussian_noise':                                                      # :272-281
+                        noise = np.random.normal(0, v * 255, a.shape).astype(np.float32)
+                        out = np.clip(a.astype(np.float32) + noise, 0, 255).astype(np.uint8)
+                    elif ttype == 'shear': out = ref_shear(img, v)                                       # :212-226
+                    elif ttype == 'contrast': out, pinned = O.apply_contrast(a, v), 0                    # cv2: unpinned
+                    else: out, pinned = O.apply_blur(a, v), 0                                            # cv2: unpinned
+                sha = hashlib.sha256(np.ascontiguousarray(np.asarray(out)).tobytes()).hexdigest()
+                fh.write(f"{seed}\t{ttype}\t{value!r}\t{fname}\t{sha}\t{pinned}\n")
 
 
 if __name__ == "__main__":

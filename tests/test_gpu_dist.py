@@ -1,0 +1,108 @@
+"""GPU: the torch.distributed / RCCL plumbing as far as one GPU allows: nccl
+(= RCCL) process group with `device_id`, barrier, all_reduce, the scatter -> op -> gather helpers
+on DEVICE tensors at world size 1, bench.py's distributed branch, and a two-rank rehearsal of the
+whole N > 1 control flow (CPU collectives over gloo, both ranks on the one GPU) including the
+scatter/gather children.  Each case runs in its own process."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+WORLD1 = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["IMGXF_ROOT"])
+from imagetransformations_amd import ops, sharding as S
+torch.cuda.set_device(0); dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+dist.barrier()
+t = torch.ones(4, device=dev); dist.all_reduce(t); assert float(t.sum()) == 4.0
+g = torch.Generator(device=dev); g.manual_seed(3)
+frames = torch.randint(0, 256, (7, 135, 480, 3), dtype=torch.uint8, device=dev, generator=g)
+fn = lambda b: ops.gaussian_blur(b, 5, 5 / 6)
+want = fn(frames)
+assert torch.equal(S.map_frames(fn, frames, 7, (135, 480, 3), dev), want)
+assert torch.equal(S.map_frames_pipelined(fn, frames, 7, (135, 480, 3), dev, chunk=2), want)
+loc = S.scatter_frames(frames, 7, (135, 480, 3), dev)
+assert torch.equal(S.gather_frames(loc, 7), frames) and S.checksum(loc) == int(frames.to(torch.int64).sum())
+dist.barrier(); dist.destroy_process_group(); print("world1 ok")
+'''
+
+
+def _env(port, **kw):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), IMGXF_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(kw)
+    return env
+
+
+def test_nccl_world1_collectives_and_sharding_on_device_tensors(device):
+    res = subprocess.run([sys.executable, "-c", WORLD1], env=_env(_free_port(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "world1 ok" in res.stdout, (res.stdout[-500:], res.stderr[-1500:])
+
+
+def _bench_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout[-500:]
+    return json.loads(lines[-1])
+
+
+def test_bench_distributed_branch_world1_nccl(device):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "4", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-extras"],
+                         env=_env(_free_port(), IMGXF_BENCH_FORCE_DIST="1"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-1500:]
+    r = _bench_line(res.stdout)
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["roofline"]["frac"] > 0
+    assert set(r["roofline_kernels"]) >= {"gaussian5x5_4k", "rotate30_zoom1.5_bilinear_4k", "gaussian5x5_1080p"}
+    assert set(r["resolutions"]) == {"3840x2160", "1920x1080"}
+    for k in r["roofline_kernels"].values():
+        assert k["ms"]["min"] <= k["ms"]["median"] <= k["ms"]["max"]
+
+
+def test_bench_two_rank_rehearsal_with_scatter_gather_children(device):
+    """World size 2 on one GPU: gloo collectives, both ranks (and their scatter/gather children)
+    share device 0 — the N > 1 control flow of bench.py end to end."""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "4", "--steps", "2", "--warmup", "1",
+           "--no-extras", "--no-1080p", "--sg-timeout", "240"]
+    res = subprocess.run(cmd, env=_env(port, IMGXF_BENCH_BACKEND="gloo", IMGXF_BENCH_SHARED_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    r = _bench_line(res.stdout)
+    assert r["n_gpus"] == 2 and r["config"]["global_frames"] == 8 and r["scaling"] == "weak"
+    sg = r["scatter_gather"]
+    assert sg.get("equal") is True and sg["frames"] == 16, sg
+
+
+def test_ops_follow_the_tensors_device_and_stream(device):
+    """launches take device and stream from the tensor.  With one GPU: a side stream is
+    honoured (the result is ordered after work queued on it); with two, a tensor on the non-current
+    device runs there."""
+    import torch
+    from imagetransformations_amd import ops
+    side = torch.cuda.Stream()
+    a = torch.zeros((4, 64, 480, 3), dtype=torch.uint8, device=device)
+    with torch.cuda.stream(side):
+        a.fill_(200)                                   # queued on the side stream only
+        out = ops.brightness(a, 0.5)                   # must be enqueued behind it on the same stream
+    side.synchronize()
+    assert int(out.min()) == 100 and int(out.max()) == 100
+    if torch.cuda.device_count() >= 2:
+        other = torch.device("cuda", 1)
+        b = torch.full((2, 32, 480, 3), 80, dtype=torch.uint8, device=other)
+        with torch.cuda.device(0):
+            r = ops.gaussian_blur(b, 5, 5 / 6)
+        assert r.device == other and int(r.min()) == 80 and int(r.max()) == 80

@@ -129,6 +129,29 @@ def test_driver_reproduces_grids_filenames_and_outputs(device):
         assert np.array_equal(got, want), ttype
 
 
+def test_driver_matches_committed_library_fixture(device):
+    """(type, value, file name, sha256) of a seeded 48x64 driver run captured from
+    Pillow / NumPy with the reference's calls (tests/golden/driver_fixture.tsv, make_golden.py): the
+    facade draws the same values, builds the same names and — for the library-pinned types — the
+    same bytes; the cv2-backed rows (pinned = 0) only pin value and name."""
+    import csv
+    import hashlib
+    from imagetransformations_amd import transformation as T
+    rows = list(csv.DictReader(open(os.path.join(os.path.dirname(__file__), "golden", "driver_fixture.tsv")), delimiter="\t"))
+    img = Image.fromarray(synth(5, 48, 64))
+    for seed in sorted({int(r["seed"]) for r in rows}):
+        want = [r for r in rows if int(r["seed"]) == seed]
+        random.seed(seed); np.random.seed(99)
+        plan = T.plan_transformations("img0")
+        random.seed(seed); np.random.seed(99)
+        outs = T.apply_all_transformations([(img, "/x/img0.png")])
+        assert len(outs) == len(want) == 8
+        for r, (ttype, args, fname), out in zip(want, plan, outs):
+            assert (r["type"], r["value"], r["filename"]) == (ttype, repr(tuple(args)), fname)
+            if r["pinned"] == "1":
+                assert hashlib.sha256(np.ascontiguousarray(np.asarray(out)).tobytes()).hexdigest() == r["sha256"], (seed, ttype)
+
+
 def test_full_size_outputs_match_committed_sha256(device):
     """Integer-exact ops at 1080p and 4K: sha256 of the HIP output == sha256 recorded from
     Pillow / SciPy in the build container (tests/golden/fullsize_sha256.tsv)."""

@@ -75,3 +75,33 @@ def test_grid_values_reproduce_the_reference_float_artefacts():
     assert len(O.grid_values("blur")) == 11 and O.grid_values("blur")[-1] == 5.0
     assert [O.blur_ksize(r) for r in O.grid_values("blur")] == [None, 3, 7, 9, 13, 15, 19, 21, 25, 27, 31]
     assert O.blur_ksize(5 / 6) == 5      # the benchmark's "5x5" under the reference's own rule
+
+
+def test_oracle_reproduces_the_driver_fixture():
+    """SURVEY §8a row H on the CPU: the oracle evaluated on the fixture's drawn values gives the
+    bytes Pillow / NumPy gave (tests/golden/driver_fixture.tsv); grids and draw order are the
+    reference's (one random.choice per type, two for translation)."""
+    import hashlib
+    import random
+    rows = list(csv.DictReader(open(os.path.join(GOLD, "driver_fixture.tsv")), delimiter="\t"))
+    assert len(rows) == 24
+    a = synth(5, 48, 64)
+    for seed in sorted({int(r["seed"]) for r in rows}):
+        random.seed(seed)
+        np.random.seed(99)
+        for r in [r for r in rows if int(r["seed"]) == seed]:
+            ttype, grid = r["type"], O.grid_values(r["type"])
+            if ttype == "translation":
+                args = (random.choice(grid), random.choice(grid))
+            else:
+                args = (random.choice(grid),)
+            assert repr(args) == r["value"]
+            if ttype == "scale": out = O.apply_scale(a, *args)
+            elif ttype == "rotation": out = O.apply_rotation(a, *args)
+            elif ttype == "lighten_darken": out = O.apply_brightness(a, *args)
+            elif ttype == "gaussian_noise": out = O.apply_gaussian_noise(a, *args)
+            elif ttype == "translation": out = O.apply_translation(a, *args)
+            elif ttype == "shear": out = O.apply_shear(a, *args)
+            elif ttype == "contrast": out = O.apply_contrast(a, *args)
+            else: out = O.apply_blur(a, *args)
+            assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == r["sha256"], (seed, ttype)

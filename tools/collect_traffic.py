@@ -1,17 +1,24 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into
-profiles/gaussian_pmc.json (mean counter value per Gaussian launch).
+profiles/traffic_pmc.json (mean counter value per launch of each timed kernel of the 4K step).
 usage: python tools/collect_traffic.py <pmc_dir> <frames_per_gpu> <out.json>"""
 import csv, glob, json, sys
 root, frames, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+KERNELS = {"sepconv": "sepconv_march_kernel", "affine_bilinear_mf": "affine_bilinear_mf_kernel"}
+acc = {k: {"FETCH_SIZE": [], "WRITE_SIZE": []} for k in KERNELS}
+px4k = frames * 2160 * 3840
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "sepconv" in row["Kernel_Name"] and row["Counter_Name"] in vals:
-            vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
-rec = {"frames_per_gpu": frames, "kernel": "sepconv_march_kernel<3,2>",
-       "FETCH_SIZE_KiB": sum(vals["FETCH_SIZE"]) / max(1, len(vals["FETCH_SIZE"])),
-       "WRITE_SIZE_KiB": sum(vals["WRITE_SIZE"]) / max(1, len(vals["WRITE_SIZE"])),
-       "launches": [len(vals["FETCH_SIZE"]), len(vals["WRITE_SIZE"])],
-       "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline"}
+        for key, sub in KERNELS.items():
+            if sub in row["Kernel_Name"] and row["Counter_Name"] in acc[key]:
+                acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
+rec = {"frames_per_gpu": frames, "kernels": {},
+       "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
+              "--steps 3 --warmup 1 --no-extras --no-cpu-baseline --no-1080p; traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB "
+              "(gfx950: FETCH_SIZE counts half the bytes of a wide 16-B-per-lane stream, MI355X_MICROARCH.md)"}
+for key, v in acc.items():
+    if v["FETCH_SIZE"] and v["WRITE_SIZE"]:
+        fe, wr = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+        rec["kernels"][key] = {"FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "launches": [len(v["FETCH_SIZE"]), len(v["WRITE_SIZE"])],
+                               "bytes_per_px_corrected": round((2 * fe + wr) * 1024 / px4k, 4)}
 json.dump(rec, open(out, "w"), indent=1)
-print(rec)
+print(json.dumps(rec, indent=1))
