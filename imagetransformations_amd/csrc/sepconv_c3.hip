@@ -6,7 +6,7 @@
 namespace imgxf {
 int sepconv_c3(int R, const View& s, const View& d, const View& df, const Taps& taps,
                int border, hipStream_t st) {
-    static const int rpw_env = getenv("IMGXF_MARCH_RPW") ? atoi(getenv("IMGXF_MARCH_RPW")) : 0;
+    const int rpw_env = getenv("IMGXF_MARCH_RPW") ? atoi(getenv("IMGXF_MARCH_RPW")) : 0;
     static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
     if (!no_march && march_eligible(s, d, df, 3, R, border)) {
         switch (R) {

@@ -200,6 +200,14 @@ int main(int argc, char** argv) {
             printf("----\n");
             continue;
         }
+        if (getenv("SKEL_RPW")) {
+            for (int rpw : {1, 2, 4, 8, 16, 32, 64, 94}) run_march<5, true, true, 0>("G1 spb4", a, b, g, 1, 4, rpw);
+            for (int rpw : {1, 4, 16, 94}) run_march<5, true, true, 0>("G1 spb12", a, b, g, 1, 12, rpw);
+            for (int rpw : {4, 16, 94}) run_march<2, true, true, 0>("G1 spb4 J2", a, b, g, 1, 4, rpw);
+            for (int rpw : {4, 16, 94}) run_march<5, false, true, 0>("G1 spb4 nohalo", a, b, g, 1, 4, rpw);
+            printf("----\n");
+            continue;
+        }
         if (getenv("SKEL_WIDE")) {
             run_march<5, true, true, 0>("G1 spb4", a, b, g, 1, 4, 94);
             run_march<5, true, true, 0>("G1 spb6", a, b, g, 1, 6, 94);
