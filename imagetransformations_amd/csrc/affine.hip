@@ -1303,7 +1303,7 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
     const bool want_f32 = dbg.p != nullptr;
     const char* fpb_env = getenv("IMGXF_AFFINE_FPB");
     const int fpb = fpb_env ? atoi(fpb_env) : 16;
-    const int afpb = fpb < 0 ? -fpb : fpb;
+    const int afpb = fpb;
     const bool mf = BHT == MF_TILE_H && !want_f32 && afpb >= 2 && d.n >= 2 && bht <= 64 &&
                     (int64_t)d.h * d.rs < ((int64_t)1 << 32);
     // LDS-DMA staging of packed rows needs 16-byte aligned source rows and a box of <= 52 x 52 pixels; it

@@ -15,7 +15,7 @@ out = torch.empty_like(frames)
 st = torch.cuda.current_stream().cuda_stream
 vs, vo = _ffi.view_of(frames), _ffi.view_of(out)
 m = _ffi.f64_array(ops.rotate_zoom_matrix(W, H, 30.0, 1.5)); fill = _ffi.u8_array([0, 0, 0])
-variants = {"per-frame kernel (fpb=1)": ("1", 0), "reg staging fpb=16": ("16", 1), "dma fpb=4": ("4", 0), "dma fpb=8": ("8", 0), "dma fpb=16": ("16", 0), "dma fpb=32": ("32", 0), "dma fpb=16 NO LOADS (timing only)": ("-16", 0)}
+variants = {"per-frame kernel (fpb=1)": ("1", 0), "reg staging fpb=16": ("16", 1), "dma fpb=4": ("4", 0), "dma fpb=8": ("8", 0), "dma fpb=16": ("16", 0), "dma fpb=32": ("32", 0)}
 
 def run(v, precise, iters=5):
     fpb, nodma = v

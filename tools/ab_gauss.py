@@ -17,20 +17,15 @@ st = torch.cuda.current_stream().cuda_stream
 vs, vo = _ffi.view_of(frames), _ffi.view_of(out)
 KNOBS = ("IMGXF_MARCH_TAIL", "IMGXF_MARCH_GROUP", "IMGXF_MARCH_SPB", "IMGXF_MARCH_NO_MIXED", "IMGXF_MARCH_RPW", "IMGXF_MARCH_U2")
 variants = {
-    "r1 (G=1, scalar H, spb4, no tail)": {"IMGXF_MARCH_GROUP": "1", "IMGXF_MARCH_NO_MIXED": "1", "IMGXF_MARCH_SPB": "4", "IMGXF_MARCH_TAIL": "0,0"},
-    "no tail": {"IMGXF_MARCH_TAIL": "0,0"},
+    "r1 (G=1, scalar H, spb4)": {"IMGXF_MARCH_GROUP": "1", "IMGXF_MARCH_NO_MIXED": "1", "IMGXF_MARCH_SPB": "4"},
     "default": {},
-    "tail 25,48": {"IMGXF_MARCH_TAIL": "25,48"},
-    "tail 25,64": {"IMGXF_MARCH_TAIL": "25,64"},
-    "tail 37,48": {"IMGXF_MARCH_TAIL": "37,48"},
-    "tail 37,64": {"IMGXF_MARCH_TAIL": "37,64"},
-    "tail 50,48": {"IMGXF_MARCH_TAIL": "50,48"},
-    "tail 50,64": {"IMGXF_MARCH_TAIL": "50,64"},
-    "rpw 135 tail 37,54": {"IMGXF_MARCH_RPW": "135", "IMGXF_MARCH_TAIL": "37,54"},
-    "rpw 180 tail 37,48": {"IMGXF_MARCH_RPW": "180", "IMGXF_MARCH_TAIL": "37,48"},
-    "rpw 180 tail 50,60": {"IMGXF_MARCH_RPW": "180", "IMGXF_MARCH_TAIL": "50,60"},
-    "rpw 64 no tail": {"IMGXF_MARCH_RPW": "64", "IMGXF_MARCH_TAIL": "0,0"},
-    "rpw 72 tail 25,36": {"IMGXF_MARCH_RPW": "72", "IMGXF_MARCH_TAIL": "25,36"},
+    "G=1": {"IMGXF_MARCH_GROUP": "1"},
+    "G=2": {"IMGXF_MARCH_GROUP": "2"},
+    "G=4": {"IMGXF_MARCH_GROUP": "4"},
+    "G=8": {"IMGXF_MARCH_GROUP": "8"},
+    "rpw 64": {"IMGXF_MARCH_RPW": "64"},
+    "rpw 135": {"IMGXF_MARCH_RPW": "135"},
+    "spb 3": {"IMGXF_MARCH_SPB": "3"},
 }
 extra = os.environ.get("AB_EXTRA")
 if extra:      # e.g. AB_EXTRA="rpw180:IMGXF_MARCH_RPW=180"
