@@ -2,6 +2,7 @@
 // (sepconv_march.inc) when rows are 16-byte aligned and the halo fits one block,
 // LDS-tiled general path (sepconv_tile.inc) otherwise.
 #include "sepconv_march4.inc"
+#include "sepconv_mfma.inc"
 #include <stdlib.h>
 namespace imgxf {
 int sepconv_c3(int R, const View& s, const View& d, const View& df, const Taps& taps,
@@ -13,6 +14,20 @@ int sepconv_c3(int R, const View& s, const View& d, const View& df, const Taps& 
 #define IMGXF_M(r) case r: return launch_sepconv_march<3, r>(s, d, df, taps, st, rpw_env);
             IMGXF_M(1) IMGXF_M(2) IMGXF_M(3) IMGXF_M(4)
 #undef IMGXF_M
+            default: break;
+        }
+    }
+    // large radii: both passes on the matrix cores (sepconv_mfma.inc).  Its time hardly depends on the radius (1.39 ms
+    // per 64 4K frames at k = 13 ... 21, 1.60 ms at k = 31) while the vector kernel grows with it (1.29 / 1.41 / 1.80 /
+    // 3.40 ms at k = 13 / 15 / 19 / 31): break-even at k = 15, so R >= 8 goes to the matrix cores
+    // (IMGXF_MFMA_MIN_R moves the threshold)
+    const char* mr = getenv("IMGXF_MFMA_MIN_R");
+    const int mfma_min_r = mr ? atoi(mr) : 8;
+    if (!no_march && R >= mfma_min_r && mfma_eligible(s, d, df, 3, R, border)) {
+        switch (R) {
+#define IMGXF_MM(r) case r: return launch_sepconv_mfma<r>(s, d, df, taps, st);
+            IMGXF_MM(2) IMGXF_MM(3) IMGXF_MM(4) IMGXF_MM(5) IMGXF_MM(6) IMGXF_MM(7) IMGXF_MM(8) IMGXF_MM(9) IMGXF_MM(10) IMGXF_MM(11) IMGXF_MM(12) IMGXF_MM(13) IMGXF_MM(14) IMGXF_MM(15)
+#undef IMGXF_MM
             default: break;
         }
     }
