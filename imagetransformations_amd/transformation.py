@@ -18,7 +18,7 @@ import numpy as np
 import torch
 from PIL import Image
 
-from . import ops
+from . import ops, staging
 
 # Where apply_all_transformations writes its JPEGs (the reference hard-codes a
 # /Users/... path at transformation.py:13-17).  None = do not write files.
@@ -48,12 +48,12 @@ def _upload(img: Image.Image) -> torch.Tensor:
     arr = np.array(img)
     if arr.dtype != np.uint8:
         raise TypeError(f"only 8-bit images are supported, got mode {img.mode!r}")
-    return torch.from_numpy(arr).to(_device(), non_blocking=False)
+    return staging.upload(arr, _device())
 
 
 def _download(t: torch.Tensor) -> Image.Image:
-    """Image.fromarray(device tensor) (synchronises on the copy)."""
-    return Image.fromarray(t.cpu().numpy())
+    """Image.fromarray(device tensor): asynchronous copy into pinned memory, wait for that copy only."""
+    return Image.fromarray(staging.download(t).numpy())
 
 
 def _hw(t: torch.Tensor):
@@ -332,8 +332,9 @@ def apply_all_transformations_batched_named(images):
         'shear': _shear_t,
         'translation': _translation_t,
     }
+    pending = []                                        # (Download, entries): results still on their way back
     for size, members in by_size.items():
-        frames = torch.from_numpy(np.stack([np.array(images[i][0]) for i in members])).to(dev)
+        frames = staging.upload([np.asarray(images[i][0]) for i in members], dev)   # one pinned block, async H2D
         groups = {}
         for row, i in enumerate(members):
             for k, (transform_type, args, _) in enumerate(plans[i]):
@@ -349,12 +350,15 @@ def apply_all_transformations_batched_named(images):
                     continue
                 out = ops.gaussian_blur(batch, ksize, args[0], fixed_point=BLUR_FIXED_POINT)
             elif transform_type == 'gaussian_noise':
-                z = torch.from_numpy(np.stack([noise[(i, k)] for _, i, k in entries])).to(dev)
+                z = staging.upload([noise[(i, k)] for _, i, k in entries], dev)
                 out = ops.add_noise(batch, z)
             else:
                 out = tensor_fns[transform_type](batch, *args)
-            host = out.cpu().numpy()
-            for j, (_, i, k) in enumerate(entries):
-                results[i][k] = Image.fromarray(host[j])
+            # queue the copy back and keep launching: the host waits per result only when it builds the images
+            pending.append((staging.download(out), entries))
+    for dl, entries in pending:
+        host = dl.numpy()
+        for j, (_, i, k) in enumerate(entries):
+            results[i][k] = Image.fromarray(host[j])
 
     return [(new_filename, results[i][k]) for i, plan in enumerate(plans) for k, (_, _, new_filename) in enumerate(plan)]

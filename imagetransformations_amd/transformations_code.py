@@ -15,7 +15,7 @@ import numpy as np
 import torch
 from PIL import Image
 
-from . import ops
+from . import ops, staging
 from .transformation import (_download, _upload, apply_blur, apply_brightness, apply_contrast,  # noqa: F401
                              apply_gaussian_noise, apply_rotation, apply_scale, apply_shear,
                              apply_translation)
@@ -205,8 +205,9 @@ def apply_all_transformations_batched(images):
         'translation': _translation_t,
         'vert_flip': lambda t: ops.flip(t),
     }
+    pending = []                                        # (Download, entries): results still on their way back
     for size, members in by_size.items():
-        frames = torch.from_numpy(np.stack([np.array(images[i][0]) for i in members])).to(dev)
+        frames = staging.upload([np.asarray(images[i][0]) for i in members], dev)     # one pinned block, async H2D
         groups = {}
         for row, i in enumerate(members):
             for k, (transform_type, args, _) in enumerate(plans[i]):
@@ -223,7 +224,7 @@ def apply_all_transformations_batched(images):
                     continue
                 out = ops.gaussian_blur(batch, ksize, args[0], fixed_point=T.BLUR_FIXED_POINT)
             elif transform_type == 'gaussian_noise':
-                z = torch.from_numpy(np.stack([extra[(i, k)] for _, i, k in entries])).to(dev)
+                z = staging.upload([extra[(i, k)] for _, i, k in entries], dev)
                 out = ops.add_noise(batch, z)
             elif transform_type == 'perspective_warp':
                 out = ops.perspective(batch, [extra[(i, k)] for _, i, k in entries])
@@ -236,9 +237,12 @@ def apply_all_transformations_batched(images):
                 out = ops.resize(torch.stack(crops), (32, 32), ops.RESAMPLE_BICUBIC)
             else:
                 out = tensor_fns[transform_type](batch, *args)
-            host = out.cpu().numpy()
-            for j, (_, i, k) in enumerate(entries):
-                results[i][k] = Image.fromarray(host[j])
+            pending.append((staging.download(out), entries))    # async copy back; the host waits per result below
+
+    for dl, entries in pending:
+        host = dl.numpy()
+        for j, (_, i, k) in enumerate(entries):
+            results[i][k] = Image.fromarray(host[j])
 
     transformed_images = []
     for i, plan in enumerate(plans):
