@@ -37,6 +37,10 @@ struct imgxf_lanczos_plan {
     // [wx, wx+ww) of the virtual out_h x out_w result; the H pass then only filters source rows
     // [ry0, ry0+rh), the ones the window's vertical taps touch
     int wx, wy, ww, wh, ry0, rh;
+    // digit tables of the fused matrix-core kernel (resample_mfma.inc); mf_nkh == 0: not usable
+    int mf_nkh, mf_ng, mf_nob, mf_nchunks;
+    int *d_mf_ws, *d_mf_kcol, *d_mf_sched, *d_mf_chunks, *d_mf_krow;
+    int8_t *d_mf_wh, *d_mf_wv;
 };
 
 namespace imgxf {
@@ -453,6 +457,8 @@ __global__ __launch_bounds__(256) void resample_v4_kernel(View s, View d, const 
     }
 }
 
+#include "resample_mfma.inc"
+
 static inline unsigned grid_for(int64_t total) {
     int64_t blocks = (total + 255) / 256;
     return (unsigned)(blocks > 16384 ? 16384 : (blocks < 1 ? 1 : blocks));
@@ -498,6 +504,31 @@ static int launch_v_fast(const imgxf_lanczos_plan* p, const View& s, const View&
     return launch_status();
 }
 
+// the fused kernel reads and writes dwords at 4-byte aligned addresses and keeps row offsets in 32 bits
+static bool rs_mf_ok(const imgxf_lanczos_plan* p, const View& s, const View& d) {
+    if (!p->mf_nkh) return false;
+    if (((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | ((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs) & 3) != 0) return false;
+    return s.rs > 0 && (int64_t)(p->ry0 + p->rh) * s.rs < (int64_t(1) << 31);
+}
+
+static int launch_rs_mf(const imgxf_lanczos_plan* p, const View& s, const View& d, hipStream_t st) {
+    RsMfArgs a;
+    a.ws = p->d_mf_ws; a.wh = (const rs_v4i*)p->d_mf_wh; a.kcol = p->d_mf_kcol; a.sched = p->d_mf_sched;
+    a.chunks = p->d_mf_chunks; a.wv = (const u8*)p->d_mf_wv; a.krow = p->d_mf_krow;
+    a.ng = p->mf_ng; a.nsets = (p->mf_ng + RSMF_WAVES - 1) / RSMF_WAVES; a.nchunks = p->mf_nchunks;
+    a.ry0 = p->ry0; a.rh = p->rh; a.out_h = d.h; a.out_rb = (int)d.rowbytes();
+    const int64_t total = (int64_t)a.nsets * a.nchunks * s.n;
+    if (total > (int64_t(1) << 30)) return IMGXF_ERR_UNSUPPORTED;
+    a.total = (unsigned)total;
+    const dim3 grid((unsigned)((total + 7) & ~int64_t(7))), block(RSMF_WAVES * 64);
+    switch (p->mf_nkh) {
+        case 1: hipLaunchKernelGGL((resample_mfma_kernel<1>), grid, block, RSMF_LDS_BYTES, st, s, d, a); break;
+        case 2: hipLaunchKernelGGL((resample_mfma_kernel<2>), grid, block, RSMF_LDS_BYTES, st, s, d, a); break;
+        default: hipLaunchKernelGGL((resample_mfma_kernel<3>), grid, block, RSMF_LDS_BYTES, st, s, d, a); break;
+    }
+    return launch_status();
+}
+
 static int launch_h(const View& s, const View& d, const int* b, const int* k, int ks, hipStream_t st) {
     const unsigned g = grid_for((int64_t)d.n * d.h * d.w);
     switch (s.c) {
@@ -517,6 +548,13 @@ static int upload(const std::vector<int>& v, int** dptr) {
     hipError_t e = hipMalloc((void**)dptr, v.size() * sizeof(int));
     if (e != hipSuccess) return (int)e;
     e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+    return e == hipSuccess ? IMGXF_OK : (int)e;
+}
+
+static int upload_bytes(const std::vector<int8_t>& v, int8_t** dptr) {
+    hipError_t e = hipMalloc((void**)dptr, v.size());
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpy(*dptr, v.data(), v.size(), hipMemcpyHostToDevice);
     return e == hipSuccess ? IMGXF_OK : (int)e;
 }
 
@@ -573,8 +611,10 @@ IMGXF_API int imgxf_resample_plan_create_window(imgxf_lanczos_plan** plan, int i
             in_h = p->rh;
         }
     }
+    std::vector<int> bxv, kxv;
     if (p->need_h) {
-        std::vector<int> b, k;
+        std::vector<int>& b = bxv;
+        std::vector<int>& k = kxv;
         p->ksx = build_coeffs(in_w, out_w_full, filter, b, k);
         slice_tables(b, k, p->ksx, wx, ww);
         if ((rc = upload(b, &p->d_bounds_x)) == IMGXF_OK) rc = upload(k, &p->d_kk_x);
@@ -632,6 +672,19 @@ IMGXF_API int imgxf_resample_plan_create_window(imgxf_lanczos_plan** plan, int i
             }
         }
     }
+    if (rc == IMGXF_OK && p->need_h && p->need_v) {
+        const char* e = getenv("IMGXF_RESAMPLE_MFMA_OC");
+        const int oc = e ? atoi(e) : 16;
+        RsMfTables t;
+        if (oc > 0 && oc <= RSMF_MAX_OC && build_rs_mf_tables(bxv, kxv, p->ksx, by, ky, p->ksy, in_w, c, in_h, out_w, out_h, oc, t)) {
+            if ((rc = upload(t.ws, &p->d_mf_ws)) == IMGXF_OK && (rc = upload(t.kcol, &p->d_mf_kcol)) == IMGXF_OK &&
+                (rc = upload(t.sched, &p->d_mf_sched)) == IMGXF_OK && (rc = upload(t.chunks, &p->d_mf_chunks)) == IMGXF_OK &&
+                (rc = upload(t.krow, &p->d_mf_krow)) == IMGXF_OK && (rc = upload_bytes(t.wh, &p->d_mf_wh)) == IMGXF_OK &&
+                (rc = upload_bytes(t.wv, &p->d_mf_wv)) == IMGXF_OK) {
+                p->mf_nkh = t.nkh; p->mf_ng = t.ng; p->mf_nob = t.nob; p->mf_nchunks = t.nchunks;
+            }
+        }
+    }
     if (rc == IMGXF_OK && p->need_h && p->need_v && max_frames > 0) {     // max_frames == 0: workspace-only plan
         hipError_t e = hipMalloc((void**)&p->d_tmp, (size_t)max_frames * p->rh * out_w * c);
         if (e != hipSuccess) rc = (int)e;
@@ -654,6 +707,13 @@ IMGXF_API int imgxf_lanczos_plan_destroy(imgxf_lanczos_plan* p) {
     if (p->d_start4_y) (void)hipFree(p->d_start4_y);
     if (p->d_pk4_y) (void)hipFree(p->d_pk4_y);
     if (p->d_tmp) (void)hipFree(p->d_tmp);
+    if (p->d_mf_ws) (void)hipFree(p->d_mf_ws);
+    if (p->d_mf_kcol) (void)hipFree(p->d_mf_kcol);
+    if (p->d_mf_sched) (void)hipFree(p->d_mf_sched);
+    if (p->d_mf_chunks) (void)hipFree(p->d_mf_chunks);
+    if (p->d_mf_krow) (void)hipFree(p->d_mf_krow);
+    if (p->d_mf_wh) (void)hipFree(p->d_mf_wh);
+    if (p->d_mf_wv) (void)hipFree(p->d_mf_wv);
     delete p;
     return IMGXF_OK;
 }
@@ -672,6 +732,12 @@ IMGXF_API int imgxf_resample_workspace_bytes(const imgxf_lanczos_plan* p, int n,
 
 static int run_resample(const imgxf_lanczos_plan* p, const imgxf_view* src, const imgxf_view* dst,
                         uint8_t* tmp, void* stream);
+
+IMGXF_API int imgxf_resample_plan_kernel(const imgxf_lanczos_plan* p, int* ksteps) {
+    if (!p || !ksteps) return IMGXF_ERR_NULL;
+    *ksteps = p->mf_nkh;
+    return IMGXF_OK;
+}
 
 IMGXF_API int imgxf_resize_lanczos_u8(const imgxf_lanczos_plan* p, const imgxf_view* src,
                                       const imgxf_view* dst, void* stream) {
@@ -716,6 +782,7 @@ static int run_resample(const imgxf_lanczos_plan* p, const imgxf_view* src, cons
         return launch_h(a, b, p->d_bounds_x, p->d_kk_x, p->ksx, st);
     };
     if (p->need_h && !p->need_v) return run_h(s, d);
+    if (!slow && rs_mf_ok(p, s, d) && !getenv("IMGXF_RESAMPLE_NO_MFMA")) return launch_rs_mf(p, s, d, st);
     View mid = s;
     if (p->need_h) {
         View sub = s;                                  // the source rows the window's vertical taps touch

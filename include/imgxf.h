@@ -160,6 +160,11 @@ int imgxf_resample_plan_create_window(imgxf_lanczos_plan** plan, int in_h, int i
 int imgxf_resample_workspace_bytes(const imgxf_lanczos_plan* plan, int n, size_t* bytes);
 int imgxf_resample_ws_u8(const imgxf_lanczos_plan* plan, const imgxf_view* src, const imgxf_view* dst,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Which kernels a two-pass plan runs on 4-byte aligned views: *ksteps = 0 -> the H and V vector
+ * kernels through the intermediate; 1..3 -> both passes fused on the i8 matrix cores
+ * (csrc/resample_mfma.inc, no intermediate traffic), the value being the 32-byte k-steps of its
+ * horizontal product.  Same bytes either way; IMGXF_RESAMPLE_NO_MFMA=1 forces the former. */
+int imgxf_resample_plan_kernel(const imgxf_lanczos_plan* plan, int* ksteps);
 
 /* ---- a6: elementwise colour maps ------------------------------------------------------*/
 /* Pillow convert('L') transformation.py:336: (19595R+38470G+7471B+0x8000)>>16. src c in {3,4}, dst c==1 */
