@@ -30,7 +30,7 @@ if ocs:
         t = statistics.median([run(1.1, False)[0] for _ in range(ROUNDS)])
         print(f"1.1x  OC={oc:3s}: {t:7.3f} ms", flush=True)
     sys.exit(0)
-for scale in (1.1, 1.3, 1.5, 0.9, 0.5):
+for scale in [float(v) for v in os.environ.get("AB_SCALES", "1.1,1.3,1.5,0.9,0.5").split(",")]:
     res = {"two-pass": [], "fused": []}
     for r in range(ROUNDS):
         t, opx = run(scale, True); res["two-pass"].append(t)
