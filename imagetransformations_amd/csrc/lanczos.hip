@@ -8,6 +8,7 @@
 #include <vector>
 #include <algorithm>
 #include <stdlib.h>
+#include <stdio.h>
 
 #define PRECISION_BITS (32 - 8 - 2)
 
@@ -508,24 +509,34 @@ static int launch_v_fast(const imgxf_lanczos_plan* p, const View& s, const View&
 static bool rs_mf_ok(const imgxf_lanczos_plan* p, const View& s, const View& d) {
     if (!p->mf_nkh) return false;
     if (((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | ((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs) & 3) != 0) return false;
-    return s.rs > 0 && (int64_t)(p->ry0 + p->rh) * s.rs < (int64_t(1) << 31);
+    return s.rs > 0 && s.rs < (1 << 24) && p->rh < (1 << 24) && (int64_t)(p->ry0 + p->rh) * s.rs < (int64_t(1) << 31);
+}
+
+template <int NW>
+static void launch_rs_mf_t(int nkh, dim3 grid, hipStream_t st, const View& s, const View& d, const RsMfArgs& a) {
+    const dim3 block(NW * 64);
+    const size_t lds = rsmf_lds_bytes(NW);
+    switch (nkh) {
+        case 1: hipLaunchKernelGGL((resample_mfma_kernel<1, NW>), grid, block, lds, st, s, d, a); break;
+        case 2: hipLaunchKernelGGL((resample_mfma_kernel<2, NW>), grid, block, lds, st, s, d, a); break;
+        default: hipLaunchKernelGGL((resample_mfma_kernel<3, NW>), grid, block, lds, st, s, d, a); break;
+    }
 }
 
 static int launch_rs_mf(const imgxf_lanczos_plan* p, const View& s, const View& d, hipStream_t st) {
+    const char* e = getenv("IMGXF_RESAMPLE_MFMA_WAVES");         // waves per workgroup, 4 or 8 (A/B knob; a wash at 4K)
+    const int nw = e && atoi(e) == 8 ? 8 : 4;
     RsMfArgs a;
     a.ws = p->d_mf_ws; a.wh = (const rs_v4i*)p->d_mf_wh; a.kcol = p->d_mf_kcol; a.sched = p->d_mf_sched;
     a.chunks = p->d_mf_chunks; a.wv = (const u8*)p->d_mf_wv; a.krow = p->d_mf_krow;
-    a.ng = p->mf_ng; a.nsets = (p->mf_ng + RSMF_WAVES - 1) / RSMF_WAVES; a.nchunks = p->mf_nchunks;
+    a.ng = p->mf_ng; a.nsets = (p->mf_ng + nw - 1) / nw; a.nchunks = p->mf_nchunks;
     a.ry0 = p->ry0; a.rh = p->rh; a.out_h = d.h; a.out_rb = (int)d.rowbytes();
     const int64_t total = (int64_t)a.nsets * a.nchunks * s.n;
     if (total > (int64_t(1) << 30)) return IMGXF_ERR_UNSUPPORTED;
     a.total = (unsigned)total;
-    const dim3 grid((unsigned)((total + 7) & ~int64_t(7))), block(RSMF_WAVES * 64);
-    switch (p->mf_nkh) {
-        case 1: hipLaunchKernelGGL((resample_mfma_kernel<1>), grid, block, RSMF_LDS_BYTES, st, s, d, a); break;
-        case 2: hipLaunchKernelGGL((resample_mfma_kernel<2>), grid, block, RSMF_LDS_BYTES, st, s, d, a); break;
-        default: hipLaunchKernelGGL((resample_mfma_kernel<3>), grid, block, RSMF_LDS_BYTES, st, s, d, a); break;
-    }
+    const dim3 grid((unsigned)((total + 7) & ~int64_t(7)));
+    if (nw == 8) launch_rs_mf_t<8>(p->mf_nkh, grid, st, s, d, a);
+    else launch_rs_mf_t<4>(p->mf_nkh, grid, st, s, d, a);
     return launch_status();
 }
 

@@ -22,6 +22,16 @@ def run(scale, no_mfma, iters=6):
     for _ in range(iters): call()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters, W * H
+shapes = os.environ.get("AB_SHAPES")
+if shapes:       # waves per workgroup "4;8" x AB_OCS chunk lengths
+    for shape in shapes.split(";"):
+        os.environ["IMGXF_RESAMPLE_MFMA_WAVES"] = shape
+        for oc in os.environ.get("AB_OCS", "16").split(","):
+            os.environ["IMGXF_RESAMPLE_MFMA_OC"] = oc
+            ops._plans.clear()
+            ts = [statistics.median([run(sc, False)[0] for _ in range(ROUNDS)]) for sc in (1.1, 1.3, 0.9)]
+            print(f"waves={shape:2s} OC={oc:3s}: 1.1x {ts[0]:6.3f}  1.3x {ts[1]:6.3f}  0.9x {ts[2]:6.3f} ms", flush=True)
+    sys.exit(0)
 ocs = os.environ.get("AB_OCS")
 if ocs:
     for oc in ocs.split(","):
