@@ -62,6 +62,7 @@ SIGNATURES = {
     "imgxf_resample_workspace_bytes": [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)],
     "imgxf_resample_ws_u8": [C.c_void_p, _VP, _VP, C.c_void_p, C.c_size_t, C.c_void_p],
     "imgxf_resample_plan_kernel": [C.c_void_p, C.POINTER(C.c_int)],
+    "imgxf_resample_workspace_bytes_for": [C.c_void_p, _VP, _VP, C.POINTER(C.c_size_t)],
     "imgxf_rgb2l_u8": [_VP, _VP, C.c_void_p],
     "imgxf_scale_abs_u8": [_VP, _VP, C.c_float, C.c_float, C.c_void_p],
     "imgxf_blend_u8": [_VP, _U8, _VP, _U8, _VP, C.c_float, C.c_void_p],

@@ -757,13 +757,27 @@ IMGXF_API int imgxf_resize_lanczos_u8(const imgxf_lanczos_plan* p, const imgxf_v
     return run_resample(p, src, dst, p->d_tmp, stream);
 }
 
+// does this call run the fused matrix-core kernel (no intermediate)?
+static bool resample_runs_fused(const imgxf_lanczos_plan* p, const imgxf_view* src, const imgxf_view* dst) {
+    if (!p->need_h || !p->need_v || !src || !dst) return false;
+    if (getenv("IMGXF_LANCZOS_SLOW") || getenv("IMGXF_RESAMPLE_NO_MFMA")) return false;
+    return rs_mf_ok(p, make_view(src), make_view(dst));
+}
+
+IMGXF_API int imgxf_resample_workspace_bytes_for(const imgxf_lanczos_plan* p, const imgxf_view* src,
+                                                 const imgxf_view* dst, size_t* bytes) {
+    if (!p || !src || !dst || !bytes) return IMGXF_ERR_NULL;
+    *bytes = resample_runs_fused(p, src, dst) ? 0 : resample_tmp_bytes(p, src->n);
+    return IMGXF_OK;
+}
+
 // Same resample with the intermediate in a caller-provided, stream-ordered workspace: the plan
 // holds only immutable coefficient tables, so one plan serves any number of streams (and any
 // batch size) concurrently and nothing is allocated or freed at call time (graph-capture safe).
 IMGXF_API int imgxf_resample_ws_u8(const imgxf_lanczos_plan* p, const imgxf_view* src, const imgxf_view* dst,
                                    void* workspace, size_t workspace_bytes, void* stream) {
     if (!p || !src) return IMGXF_ERR_NULL;
-    const size_t need = resample_tmp_bytes(p, src->n);
+    const size_t need = resample_runs_fused(p, src, dst) ? 0 : resample_tmp_bytes(p, src->n);
     if (need && (!workspace || workspace_bytes < need)) return IMGXF_ERR_WORKSPACE;
     return run_resample(p, src, dst, (uint8_t*)workspace, stream);
 }
@@ -793,7 +807,7 @@ static int run_resample(const imgxf_lanczos_plan* p, const imgxf_view* src, cons
         return launch_h(a, b, p->d_bounds_x, p->d_kk_x, p->ksx, st);
     };
     if (p->need_h && !p->need_v) return run_h(s, d);
-    if (!slow && rs_mf_ok(p, s, d) && !getenv("IMGXF_RESAMPLE_NO_MFMA")) return launch_rs_mf(p, s, d, st);
+    if (resample_runs_fused(p, src, dst)) return launch_rs_mf(p, s, d, st);
     View mid = s;
     if (p->need_h) {
         View sub = s;                                  // the source rows the window's vertical taps touch

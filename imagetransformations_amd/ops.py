@@ -313,11 +313,12 @@ _plans = _PlanCache()
 def _run_plan(plan, t: torch.Tensor, out: torch.Tensor, n: int) -> None:
     import ctypes
     nbytes = ctypes.c_size_t()
-    F.call("imgxf_resample_workspace_bytes", plan, n, ctypes.byref(nbytes))
-    ws = torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8, device=t.device)
+    vs, vo = F.view_of(t), F.view_of(out)
+    F.call("imgxf_resample_workspace_bytes_for", plan, F.vp(vs), F.vp(vo), ctypes.byref(nbytes))   # 0: fused kernel
+    ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=t.device) if nbytes.value else None
     with torch.cuda.device(t.device):
-        F.call("imgxf_resample_ws_u8", plan, F.vp(F.view_of(t)), F.vp(F.view_of(out)), ws.data_ptr(), int(nbytes.value),
-               torch.cuda.current_stream(t.device).cuda_stream)
+        F.call("imgxf_resample_ws_u8", plan, F.vp(vs), F.vp(vo), ws.data_ptr() if ws is not None else None,
+               int(nbytes.value), torch.cuda.current_stream(t.device).cuda_stream)
 
 
 def resize_lanczos(t: torch.Tensor, size: tuple[int, int]) -> torch.Tensor:

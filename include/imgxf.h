@@ -160,6 +160,10 @@ int imgxf_resample_plan_create_window(imgxf_lanczos_plan** plan, int in_h, int i
 int imgxf_resample_workspace_bytes(const imgxf_lanczos_plan* plan, int n, size_t* bytes);
 int imgxf_resample_ws_u8(const imgxf_lanczos_plan* plan, const imgxf_view* src, const imgxf_view* dst,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The workspace THIS call needs: 0 when the two views let the fused kernel run (see
+ * imgxf_resample_plan_kernel), else imgxf_resample_workspace_bytes(plan, src->n). */
+int imgxf_resample_workspace_bytes_for(const imgxf_lanczos_plan* plan, const imgxf_view* src,
+                                       const imgxf_view* dst, size_t* bytes);
 /* Which kernels a two-pass plan runs on 4-byte aligned views: *ksteps = 0 -> the H and V vector
  * kernels through the intermediate; 1..3 -> both passes fused on the i8 matrix cores
  * (csrc/resample_mfma.inc, no intermediate traffic), the value being the 32-byte k-steps of its

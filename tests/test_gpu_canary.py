@@ -149,8 +149,33 @@ def test_sobel_mask_and_pointwise_write_only_their_destination(device):
 
 
 @pytest.mark.parametrize("scale", [1.1, 0.9, 1.3])
-def test_resample_writes_only_destination_and_workspace(device, scale):
+def test_fused_resample_writes_only_destination(device, scale):
+    """The matrix-core kernel: padded destination rows, no workspace at all (NULL is accepted)."""
     from imagetransformations_amd import _ffi as F, ops
+    st = torch.cuda.current_stream().cuda_stream
+    n, h, w = 3, 135, 240
+    t = _dev(_batch(931, n, h, w), device)
+    nw, nh = int(w * scale), int(h * scale)
+    dense = ops.resize_lanczos(t, (nw, nh)).cpu().numpy()
+    plan = ctypes.c_void_p()
+    F.call("imgxf_resample_plan_create", ctypes.byref(plan), h, w, nh, nw, 3, 0, 1)
+    try:
+        k, nbytes = ctypes.c_int(), ctypes.c_size_t(1)
+        F.call("imgxf_resample_plan_kernel", plan, ctypes.byref(k))
+        assert k.value > 0
+        g = Guarded(device, n, nh, nw, 3, row_pad=16, frame_pad=32)
+        F.call("imgxf_resample_workspace_bytes_for", plan, F.vp(F.view_of(t)), F.vp(g.view), ctypes.byref(nbytes))
+        assert nbytes.value == 0
+        F.call("imgxf_resample_ws_u8", plan, F.vp(F.view_of(t)), F.vp(g.view), None, 0, st)
+        g.check(dense, "fused lanczos")
+    finally:
+        F.call("imgxf_lanczos_plan_destroy", plan)
+
+
+@pytest.mark.parametrize("scale", [1.1, 0.9, 1.3])
+def test_resample_writes_only_destination_and_workspace(device, scale, monkeypatch):
+    from imagetransformations_amd import _ffi as F, ops
+    monkeypatch.setenv("IMGXF_RESAMPLE_NO_MFMA", "1")       # the two-pass kernels and their intermediate
     st = torch.cuda.current_stream().cuda_stream
     n, h, w = 3, 135, 240
     t = _dev(_batch(930, n, h, w), device)
