@@ -1315,9 +1315,10 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
     if (dma) {
         const dim3 grid((unsigned)(ntx * ntyt), (unsigned)((d.n + afpb - 1) / afpb));
         // RGBX pitch 56: fewest bank conflicts of the multiples of 4 (simulated for 30 deg / 1.5x: 4.0 vs 5.8 LDS cycles per gather read at 52)
-        const size_t lds = (size_t)52 * 56 * 4 + 3 * ((size_t)52 * nch * 16 + 64);
-        if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch);
-        else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch);
+        const int npk = getenv("IMGXF_AFFINE_PK3") ? 3 : 2;        // packed-row buffers (A/B knob)
+        const size_t lds = (size_t)52 * 56 * 4 + npk * ((size_t)52 * nch * 16 + 64);
+        if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch, npk);
+        else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch, npk);
         return launch_status();
     }
     // the kernel's interior test (bilinear_tile<.., BHT, true>) with the same integers
@@ -1344,11 +1345,11 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
         const dim3 grid((unsigned)(ntx * ntyt), (unsigned)((d.n + afpb - 1) / afpb));
         const size_t lds = (size_t)2 * PITCH * (bht <= 52 ? 52 : 64) * 4 + 16;     // all 4 * NBR rows are written
         if (bht <= 52) {
-            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
-            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
+            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0);
+            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0);
         } else {
-            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
-            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0);
+            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0);
+            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0);
         }
         IMGXF_CHECK(launch_status());
     } else if (list.n < ntx * ntyt) {                // at least one interior tile

@@ -55,6 +55,8 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
             if (KIND == 37) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) % CHAINS]), "v"(seed));
             if (KIND == 38) asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]) : "vcc");
             if (KIND == 39) asm volatile("v_cmp_lt_u32 s[20:21], %1, %2\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]) : "s20", "s21");
+            if (KIND == 40) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(u[(i + 1) % CHAINS]), "v"(seed));
+            if (KIND == 41) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(u[(i + 1) % CHAINS]), "v"(seed));
             if (KIND == 27) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
         }
     }
@@ -77,6 +79,7 @@ template <int KIND> void run(const char* name) {
     printf("%-20s %8.3f ms  -> %6.2f cycles per wave64 instruction per SIMD at 2.4 GHz\n", name, ms, ms * 1e-3 * 2.4e9 / per_simd);
 }
 int main() {
+    run<40>("v_fma_mix_f32 hi"); run<41>("v_fma_mix_f32 lo"); run<37>("v_fmac_f32");
     run<0>("v_fma_f32"); run<1>("v_cvt_f32_ubyte1"); run<2>("v_add_u32"); run<12>("v_cndmask_b32"); run<14>("v_cmp_lt_u32");
     run<8>("v_alignbit_b32"); run<7>("v_cvt_pk_u8_f32"); run<15>("v_mov_b32_dpp wave_shr");
     run<6>("v_pk_fma_f32"); run<3>("v_add_f64"); run<13>("v_mul_f64"); run<4>("v_fma_f64"); run<9>("v_floor_f64"); run<10>("v_cvt_i32_f64");
