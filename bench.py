@@ -394,7 +394,21 @@ def main():
         t_g = event_ms(lambda: ops.gaussian_blur(sub, 5, 5.0 / 6.0), 5)
         extras["gaussian5x5_4k_back_to_back"] = {"Mpix/s": round(npx / t_g / 1e3, 1), "frames": int(sub.shape[0]),
                                                  "roofline_frac": round(GAUSS_BYTES_PER_PX * npx / (t_g * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        del sub, out
+        # the other transforms of the reference's grid (transformation.py:95-105) on the same frames
+        from imagetransformations_amd.transformation import _scale_t
+        sub16 = sub[:16]
+        n16 = sub16.shape[0] * H4K * W4K
+        t_sc = event_ms(lambda: _scale_t(sub16, 1.1), 5)          # apply_scale 1.1x: Lanczos resize + centre crop
+        extras["apply_scale_1.1_lanczos_crop_4k"] = {"Mpix/s": round(n16 / t_sc / 1e3, 1), "frames": int(sub16.shape[0]),
+                                                     "kernel": "resample_mfma_kernel (both passes on the i8 matrix cores)",
+                                                     "roofline_frac": round(6.0 * n16 / (t_sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        t_nn = event_ms(lambda: ops.rotate(sub, 22.5, ops.NEAREST, (0, 0, 0)), 5)     # apply_rotation
+        extras["apply_rotation_22.5_nearest_4k"] = {"Mpix/s": round(npx / t_nn / 1e3, 1), "frames": int(sub.shape[0])}
+        t_b = event_ms(lambda: ops.gaussian_blur(sub, 31, 5.0), 3)                   # apply_blur, radius 5.0 -> k = 31
+        extras["gaussian31x31_4k"] = {"Mpix/s": round(npx / t_b / 1e3, 1), "frames": int(sub.shape[0]),
+                                      "kernel": "sepconv_mfma_rgb_kernel (f16 matrix cores)",
+                                      "roofline_frac": round(GAUSS_BYTES_PER_PX * npx / (t_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del sub, sub16, out
         torch.cuda.empty_cache()
         result["ops"] = extras
 

@@ -23,6 +23,7 @@ struct AffineParams {
     u32 ntx_magic;    // ceil(2^32 / ntx) of the LDS kernels' tile grid
     int sx[4], sy[4]; // round(k*q0 / 2^16), round(k*q3 / 2^16): 8.24 steps to pixel k of a lane (LDS fast loop)
     u8 fill[4];
+    int strip_w;      // NEAREST DMA kernel: > 0 = every XCD owns a vertical strip of this many tile columns
 };
 
 // ---- arithmetic policies -------------------------------------------------------------
@@ -928,7 +929,14 @@ __global__ __launch_bounds__(256) void affine_nearest_dma_kernel(View s, View d,
     const int orig = blockIdx.x, xcd = orig & 7, q = nblocks >> 3, r = nblocks & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     const int f = blockIdx.y;
-    const int tyb = P.ntx_magic ? (int)__umulhi((u32)logical, P.ntx_magic) : logical, txb = logical - tyb * ntx;
+    int tyb = P.ntx_magic ? (int)__umulhi((u32)logical, P.ntx_magic) : logical, txb = logical - tyb * ntx;
+    if (P.strip_w) {
+        // vertical strips: a tile's box overlaps its neighbours' (2x for a pure rotation); inside a strip
+        // walked row by row both neighbours are a few workgroups away on the same L2
+        const int l = orig >> 3;
+        tyb = l / P.strip_w; txb = xcd * P.strip_w + (l - tyb * P.strip_w);
+        if (txb >= ntx || tyb >= nty) return;
+    }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lx = (lane % TXG) * 4;
     const int x0 = txb * BW + lx;
@@ -1291,8 +1299,9 @@ namespace imgxf {
 constexpr int BILINEAR_TALL_NOT_TAKEN = 1 << 30;
 
 template <int BHT, int PITCH, int MAXROWS>
-static int launch_bilinear_tall(const View& s, const View& d, const AffineParams& P, const View& dbg, const double* m,
+static int launch_bilinear_tall(const View& s, const View& d, const AffineParams& Pin, const View& dbg, const double* m,
                                 int bw, int bh, int ntx, bool pr, hipStream_t st) {
+    const AffineParams& P = Pin;
     const int bwt = (int)ceil(fabs(m[0]) * 31 + fabs(m[1]) * (BHT - 1)) + 4;
     const int bht = (int)ceil(fabs(m[3]) * 31 + fabs(m[4]) * (BHT - 1)) + 4;
     const int ntyt = (d.h + BHT - 1) / BHT;
@@ -1313,12 +1322,14 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
                      ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 15) == 0 && s.w * 3 >= 16 &&
                      (int64_t)s.h * s.rs < ((int64_t)1 << 32);
     if (dma) {
-        const dim3 grid((unsigned)(ntx * ntyt), (unsigned)((d.n + afpb - 1) / afpb));
+        dim3 grid((unsigned)(ntx * ntyt), (unsigned)((d.n + afpb - 1) / afpb));
         // RGBX pitch 56: fewest bank conflicts of the multiples of 4 (simulated for 30 deg / 1.5x: 4.0 vs 5.8 LDS cycles per gather read at 52)
         const int npk = getenv("IMGXF_AFFINE_PK3") ? 3 : 2;        // packed-row buffers (A/B knob)
+        AffineParams Ps = Pin;
+        if (ntx >= 16 && !getenv("IMGXF_AFFINE_NO_STRIPS")) { Ps.strip_w = (ntx + 7) / 8; grid.x = (unsigned)(8 * Ps.strip_w * ntyt); }
         const size_t lds = (size_t)52 * 56 * 4 + npk * ((size_t)52 * nch * 16 + 64);
-        if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch, npk);
-        else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, 56, 13, true>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, nch, npk);
+        if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, 56, 13, true>), grid, dim3(256), lds, st, s, d, Ps, ntx, ntyt, fpb, nch, npk);
+        else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, 56, 13, true>), grid, dim3(256), lds, st, s, d, Ps, ntx, ntyt, fpb, nch, npk);
         return launch_status();
     }
     // the kernel's interior test (bilinear_tile<.., BHT, true>) with the same integers
@@ -1424,7 +1435,10 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
                 static const bool no_tall = getenv("IMGXF_AFFINE_NO_TALL") != nullptr;
                 if (bw64 <= 64 && bh64 <= 80 && !no_tall) {
                     const int nty64 = (d.h + 63) / 64;
-                    hipLaunchKernelGGL((affine_nearest_dma_kernel<64, 13>), dim3((unsigned)(ntx * nty64), (unsigned)d.n), dim3(256),
+                    unsigned gx = (unsigned)(ntx * nty64);
+                    // vertical strips per XCD (3 % at 4K: 0.86 -> 0.83 ms per 64 frames); IMGXF_AFFINE_NO_STRIPS = row-major ranges
+                    if (ntx >= 16 && !getenv("IMGXF_AFFINE_NO_STRIPS")) { P.strip_w = (ntx + 7) / 8; gx = (unsigned)(8 * P.strip_w * nty64); }
+                    hipLaunchKernelGGL((affine_nearest_dma_kernel<64, 13>), dim3(gx, (unsigned)d.n), dim3(256),
                                        (size_t)13 * 16 * bh64 + 32, st, s, d, P, ntx, nty64);
                 } else {
                     hipLaunchKernelGGL((affine_nearest_dma_kernel<32, 11>), grid, dim3(256), (size_t)11 * 16 * bh + 32, st, s, d, P, ntx, nty);

@@ -16,6 +16,8 @@ st = torch.cuda.current_stream().cuda_stream
 vs, vo = _ffi.view_of(frames), _ffi.view_of(out)
 m = _ffi.f64_array(ops.rotate_zoom_matrix(W, H, 30.0, 1.5)); fill = _ffi.u8_array([0, 0, 0])
 variants = {"per-frame kernel (fpb=1)": ("1", 0), "reg staging fpb=16": ("16", 1), "dma fpb=4": ("4", 0), "dma fpb=8": ("8", 0), "dma fpb=16": ("16", 0), "dma fpb=32": ("32", 0)}
+if os.environ.get("AB_STRIPS"):  # tile order: row-major ranges vs vertical strips per XCD
+    variants = {"dma fpb=16 row-major ranges": ("16", 0, None, None), "dma fpb=16 strips": ("16", 0, None, "1")}
 if os.environ.get("AB_PK"):      # two vs three packed-row buffers
     variants = {"dma fpb=16, 3 packed buffers": ("16", 0, "3"), "dma fpb=16, 2 packed buffers": ("16", 0, None),
                 "dma fpb=8, 2 packed buffers": ("8", 0, None), "dma fpb=32, 2 packed buffers": ("32", 0, None)}
@@ -24,6 +26,8 @@ def run(v, precise, iters=5):
     fpb, nodma = v[0], v[1]
     if len(v) > 2 and v[2]: os.environ["IMGXF_AFFINE_PK3"] = "1"
     else: os.environ.pop("IMGXF_AFFINE_PK3", None)
+    if len(v) > 3 and v[3]: os.environ.pop("IMGXF_AFFINE_NO_STRIPS", None)
+    elif os.environ.get("AB_STRIPS"): os.environ["IMGXF_AFFINE_NO_STRIPS"] = "1"
     os.environ["IMGXF_AFFINE_FPB"] = fpb
     if nodma: os.environ["IMGXF_AFFINE_NO_DMA"] = "1"
     else: os.environ.pop("IMGXF_AFFINE_NO_DMA", None)
