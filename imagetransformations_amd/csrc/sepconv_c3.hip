@@ -17,12 +17,12 @@ int sepconv_c3(int R, const View& s, const View& d, const View& df, const Taps& 
             default: break;
         }
     }
-    // large radii: both passes on the matrix cores (sepconv_mfma.inc).  Its time hardly depends on the radius (1.39 ms
-    // per 64 4K frames at k = 13 ... 21, 1.60 ms at k = 31) while the vector kernel grows with it (1.29 / 1.41 / 1.80 /
-    // 3.40 ms at k = 13 / 15 / 19 / 31): break-even at k = 15, so R >= 8 goes to the matrix cores
-    // (IMGXF_MFMA_MIN_R moves the threshold)
+    // large radii: both passes on the matrix cores (sepconv_mfma.inc, sepconv_mfma2_rgb_kernel).  Its time hardly depends
+    // on the radius (1.08 - 1.14 ms per 64 4K frames at k = 13 ... 21, 1.29 - 1.32 ms at k = 25 ... 31) while the vector
+    // kernel grows with it (1.30 / 1.46 / 1.84 / 3.30 ms at k = 13 / 15 / 19 / 31; 0.85 ms at k = 9): R >= 6 goes to the
+    // matrix cores (IMGXF_MFMA_MIN_R moves the threshold)
     const char* mr = getenv("IMGXF_MFMA_MIN_R");
-    const int mfma_min_r = mr ? atoi(mr) : 8;
+    const int mfma_min_r = mr ? atoi(mr) : 6;
     if (!no_march && R >= mfma_min_r && mfma_eligible(s, d, df, 3, R, border)) {
         switch (R) {
 #define IMGXF_MM(r) case r: return launch_sepconv_mfma<r>(s, d, df, taps, st);

@@ -60,3 +60,37 @@ def test_mfma_equals_vector_kernel_up_to_rounding(device, monkeypatch):
         monkeypatch.delenv("IMGXF_MFMA_MIN_R")
         d = np.abs(m.astype(int) - v.astype(int))
         assert d.max() <= 1 and (d != 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize("hw", [(37, 352), (129, 112), (270, 480)])
+@pytest.mark.parametrize("radius", [2.0, 3.5, 5.0])
+def test_lds_staged_mfma_kernel_still_within_contract(device, monkeypatch, hw, radius):
+    """IMGXF_MFMA_V1 selects the first structure (LDS-staged 128-byte tiles); the default is the wave-owned one."""
+    from imagetransformations_amd import ops
+    monkeypatch.setenv("IMGXF_MFMA_V1", "1")
+    a = synth(33, *hw)
+    k = O.blur_ksize(radius)
+    out, f32 = ops.gaussian_blur(dev(a, device), k, radius, return_f32=True)
+    assert_quantised_close(host(out), host(f32), O.gaussian_blur_f64(a, k, radius), O.saturate_u8)
+
+
+def test_mfma_row_chunks_and_full_size_agree(device, monkeypatch):
+    """Chunk length only changes which workgroup computes a row; 4K frames against the vector kernel."""
+    from imagetransformations_amd import ops
+    a = dev(np.stack([synth(90 + i, 300, 512) for i in range(2)]), device)
+    k = O.blur_ksize(4.0)
+    ref = host(ops.gaussian_blur(a, k, 4.0))
+    for bpc in ("1", "2", "3", "100"):
+        monkeypatch.setenv("IMGXF_MFMA2_BPC", bpc)
+        assert np.array_equal(host(ops.gaussian_blur(a, k, 4.0)), ref), bpc
+    monkeypatch.delenv("IMGXF_MFMA2_BPC")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    t = torch.randint(0, 256, (2, 2160, 3840, 3), dtype=torch.uint8, generator=g).to(device)
+    for radius in (2.0, 5.0):
+        k = O.blur_ksize(radius)
+        m = ops.gaussian_blur(t, k, radius)
+        monkeypatch.setenv("IMGXF_MFMA_MIN_R", "99")
+        v = ops.gaussian_blur(t, k, radius)
+        monkeypatch.delenv("IMGXF_MFMA_MIN_R")
+        d = (m.int() - v.int()).abs()
+        assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-3

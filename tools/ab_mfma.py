@@ -29,6 +29,29 @@ if os.environ.get("AB_SHAPES"):
         t = statistics.median([run(31, 5.0, 2) for _ in range(3)])
         print(f"k=31 fpw,bpc = {shape:6s}: {t:7.3f} ms", flush=True)
     sys.exit(0)
+if os.environ.get("AB_V2"):         # wave-owned columns (sepconv_mfma2) vs LDS-staged tiles (v1)
+    bpcs = os.environ.get("AB_BPC", "").split(",") if os.environ.get("AB_BPC") else [None]
+    for k, sigma in ((13, 2.0), (17, 2.5), (19, 3.0), (25, 4.0), (31, 5.0)):
+        a = []
+        os.environ["IMGXF_MFMA_V1"] = "1"
+        for r in range(ROUNDS): a.append(run(k, sigma, 2))
+        os.environ.pop("IMGXF_MFMA_V1", None)
+        line = f"k={k:2d}  v1 {statistics.median(a):7.3f} ms"
+        for bpc in bpcs:
+            if bpc: os.environ["IMGXF_MFMA2_BPC"] = bpc
+            b = [run(k, sigma, 2) for r in range(ROUNDS)]
+            line += f"   v2{' bpc=' + bpc if bpc else ''} {statistics.median(b):7.3f} ms"
+        os.environ.pop("IMGXF_MFMA2_BPC", None)
+        print(line, flush=True)
+    sys.exit(0)
+if os.environ.get("AB_HREG"):       # H operand tables from LDS vs registers
+    for k, sigma in ((13, 2.0), (19, 3.0), (25, 4.0), (31, 5.0)):
+        a, b = [], []
+        for r in range(ROUNDS):
+            os.environ["IMGXF_MFMA_NO_HREG"] = "1"; a.append(run(k, sigma, 2))
+            os.environ.pop("IMGXF_MFMA_NO_HREG", None); b.append(run(k, sigma, 2))
+        print(f"k={k:2d}  H tables in LDS {statistics.median(a):7.3f} ms   in registers {statistics.median(b):7.3f} ms", flush=True)
+    sys.exit(0)
 for k, sigma in ((5, 5 / 6), (7, 1.0), (9, 1.5), (13, 2.0), (15, 2.5), (19, 3.0), (21, 3.5), (25, 4.0), (27, 4.5), (31, 5.0)):
     res = {"vector": [], "mfma": []}
     for r in range(ROUNDS):
