@@ -406,7 +406,7 @@ def main():
         extras["apply_rotation_22.5_nearest_4k"] = {"Mpix/s": round(npx / t_nn / 1e3, 1), "frames": int(sub.shape[0])}
         t_b = event_ms(lambda: ops.gaussian_blur(sub, 31, 5.0), 3)                   # apply_blur, radius 5.0 -> k = 31
         extras["gaussian31x31_4k"] = {"Mpix/s": round(npx / t_b / 1e3, 1), "frames": int(sub.shape[0]),
-                                      "kernel": "sepconv_mfma_rgb_kernel (f16 matrix cores)",
+                                      "kernel": "sepconv_mfma2_rgb_kernel (f16 matrix cores)",
                                       "roofline_frac": round(GAUSS_BYTES_PER_PX * npx / (t_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         del sub, sub16, out
         torch.cuda.empty_cache()
