@@ -7,7 +7,7 @@ from imagetransformations_amd import _ffi, ops
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-H, W = 2160, 3840
+H, W = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (2160, 3840)
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(1)
 frames = torch.randint(0, 256, (F, H, W, 3), dtype=torch.uint8, device=dev, generator=g)
