@@ -86,6 +86,7 @@ SIGNATURES = {
     "imgxf_enhance_contrast_u8": [_VP, _VP, C.c_float, C.c_void_p, C.c_void_p],
     "imgxf_fill_u8": [_VP, _U8, C.c_void_p],
     "imgxf_copy_rect_u8": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "imgxf_translate_u8": [_VP, _VP, C.c_int, C.c_int, _U8, C.c_void_p],
     "imgxf_rot90_u8": [_VP, _VP, C.c_int, C.c_void_p],
     "imgxf_flip_u8": [_VP, _VP, C.c_int, C.c_void_p],
     "imgxf_f32_map": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p],

@@ -389,6 +389,17 @@ def copy_rect(src: torch.Tensor, dst: torch.Tensor, sx: int, sy: int, dx: int, d
     _launch(src, "imgxf_copy_rect_u8", F.vp(F.view_of(src)), F.vp(F.view_of(dst)), sx, sy, dx, dy, rw, rh)
 
 
+def translate(t: torch.Tensor, dx: int, dy: int, fillcolor=(0, 0, 0)) -> torch.Tensor:
+    """out(x, y) = t(x - dx, y - dy) where that exists, else `fillcolor`: Image.new + crop + paste of
+    apply_translation (transformation.py:284-307) in one pass."""
+    t = _check_u8(t)
+    _, _, c = _hwc(t)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    if out.numel():
+        _launch(t, "imgxf_translate_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), int(dx), int(dy), _fill_bytes(fillcolor, c))
+    return out
+
+
 def crop(t: torch.Tensor, box: tuple[int, int, int, int]) -> torch.Tensor:
     """Image.crop((left, top, right, bottom)) for boxes inside the image."""
     l, tp, r, b = box

@@ -167,15 +167,9 @@ def apply_gaussian_noise(img: Image.Image, noise_std: float) -> Image.Image:
 
 # ------------------------------------------------------------------ translation (:284-307)
 def _translation_t(t: torch.Tensor, tx: float, ty: float) -> torch.Tensor:
-    height, width = _hw(t)
-    result = ops.new(t, height, width, (0, 0, 0))
-    paste_x, paste_y = int(tx), int(ty)
-    crop_left, crop_top = max(0, -paste_x), max(0, -paste_y)
-    crop_right, crop_bottom = min(width, width - paste_x), min(height, height - paste_y)
-    if crop_left < crop_right and crop_top < crop_bottom:
-        ops.copy_rect(t, result, crop_left, crop_top, max(0, paste_x), max(0, paste_y),
-                      crop_right - crop_left, crop_bottom - crop_top)
-    return result
+    """:284-307: black canvas, crop of what stays visible, paste at max(0, int(t)) — i.e. every pixel moves by
+    (int(tx), int(ty)) and what moves in from outside is black; one kernel instead of fill + copy."""
+    return ops.translate(t, int(tx), int(ty), (0, 0, 0))
 
 
 def apply_translation(img: Image.Image, tx: float, ty: float) -> Image.Image:

@@ -263,6 +263,10 @@ int imgxf_fill_u8(const imgxf_view* dst, const uint8_t* color, void* stream);
 /* Copy the rectangle (sx,sy,rw,rh) of src to (dx,dy) of dst for every frame (same n, c). */
 int imgxf_copy_rect_u8(const imgxf_view* src, const imgxf_view* dst, int sx, int sy, int dx,
                        int dy, int rw, int rh, void* stream);
+/* apply_translation (transformation.py:284-307: Image.new(black) + crop + paste) in one pass:
+ * dst(x, y) = src(x - dx, y - dy) where that pixel exists, else fill[c] (HOST pointer).  Same n,h,w,c. */
+int imgxf_translate_u8(const imgxf_view* src, const imgxf_view* dst, int dx, int dy,
+                       const uint8_t* fill, void* stream);
 /* Image.transpose(ROTATE_90/180/270) fast paths of Image.rotate (PIL/Image.py:2513-2521).
  * quarter_turns_ccw in {1,2,3}. */
 int imgxf_rot90_u8(const imgxf_view* src, const imgxf_view* dst, int quarter_turns_ccw,

@@ -1,0 +1,61 @@
+"""apply_translation (/root/reference/transformation.py:284-307: black canvas + crop + paste) as one kernel,
+and the destination-aligned rectangle copy behind Image.crop / Image.paste: bit-exact against the oracle for
+every shift direction, shifts past the image, channel counts, strided views and padded destinations."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth
+from oracle import imgxf_oracle as O
+from test_gpu_parity import dev, host
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (37, 61), (270, 480), (65, 1283)])
+def test_translation_bit_exact(device, hw):
+    from imagetransformations_amd import ops
+    from imagetransformations_amd import transformation as T
+    a = synth(300, *hw)
+    t = dev(a, device)
+    h, w = hw
+    for tx, ty in [(0, 0), (5, 0), (-5, 0), (0, 7), (0, -7), (50, -50), (-45.7, 33.2), (w - 1, h - 1), (-(w - 1), 3),
+                   (w, 0), (0, -h), (3 * w, 2), (1, 1), (-16, -16), (16, 16)]:
+        assert np.array_equal(host(T._translation_t(t, tx, ty)), O.apply_translation(a, tx, ty)), (tx, ty)
+    got = host(ops.translate(t, 4, -3, (9, 8, 7)))
+    want = np.empty_like(a); want[:] = (9, 8, 7)
+    want[:h - 3, 4:] = a[3:, :w - 4]
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("c", [1, 4])
+def test_translation_other_channel_counts_batches_and_views(device, c):
+    from imagetransformations_amd import ops
+    rng = np.random.default_rng(c)
+    a = rng.integers(0, 256, (5, 70, 131, c), dtype=np.uint8)
+    t = torch.from_numpy(a).to(device)
+    for dx, dy in [(7, -9), (-130, 69), (0, 0)]:
+        got = ops.translate(t, dx, dy, tuple(range(1, c + 1))).cpu().numpy()
+        want = np.empty_like(a); want[:] = np.arange(1, c + 1, dtype=np.uint8)
+        ys0, ys1, xs0, xs1 = max(0, -dy), min(70, 70 - dy), max(0, -dx), min(131, 131 - dx)
+        if ys0 < ys1 and xs0 < xs1:
+            want[:, ys0 + dy:ys1 + dy, xs0 + dx:xs1 + dx] = a[:, ys0:ys1, xs0:xs1]
+        assert np.array_equal(got, want), (dx, dy)
+    big = torch.from_numpy(rng.integers(0, 256, (6, 80, 150, c), dtype=np.uint8)).to(device)
+    view = big[::2, 5:75, 10:141]                                   # strided frames and rows, unaligned base
+    assert torch.equal(ops.translate(view, 3, 4), ops.translate(view.contiguous(), 3, 4))
+
+
+def test_crop_and_paste_at_every_alignment(device):
+    """copy_rect cuts its chunks on the destination's 16-byte grid; every (source, destination) byte phase."""
+    from imagetransformations_amd import ops
+    a = synth(310, 40, 200)
+    t = dev(a, device)
+    for sx in range(0, 7):
+        for dx in range(0, 6):
+            for rw in (1, 5, 17, 64, 150):
+                canvas = torch.full((40, 230, 3), 77, dtype=torch.uint8, device=device)
+                ops.copy_rect(t, canvas, sx, 3, dx, 2, rw, 30)
+                want = np.full((40, 230, 3), 77, np.uint8)
+                want[2:32, dx:dx + rw] = a[3:33, sx:sx + rw]
+                assert np.array_equal(canvas.cpu().numpy(), want), (sx, dx, rw)
