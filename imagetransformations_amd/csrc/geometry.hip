@@ -127,9 +127,55 @@ __global__ __launch_bounds__(256) void flip_kernel(View s, View d, int mode) {
     }
 }
 
+// Mirrors on whole dwords.  FLIP_TOP_BOTTOM is a row copy in reverse row order (16-byte chunks cut on the
+// destination grid, unaligned loads); FLIP_LEFT_RIGHT of packed RGB moves groups of 4 pixels = 3 dwords:
+// destination group g is source group G-1-g with its pixels reversed, four v_perm_b32 per group
+// (a = R0G0B0R1  b = G1B1R2G2  c = B2R3G3B3  ->  R3G3B3R2  G2B2R1G1  B1R0G0B0).
+typedef u32 u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+
+__global__ __launch_bounds__(256) void flip_rows_kernel(View s, View d) {
+    const int rowbytes = d.w * d.c;
+    const int nchunks = (rowbytes + 30) >> 4;
+    const int64_t total = (int64_t)d.n * d.h * nchunks;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(t % nchunks);
+        const int64_t r = t / nchunks;
+        const int y = (int)(r % d.h), f = (int)(r / d.h);
+        const u8* sp0 = s.row(f, s.h - 1 - y);
+        u8* dp0 = d.row(f, y);
+        const int lead = (int)((uintptr_t)dp0 & 15);
+        const int b0 = ck * 16 - lead, b1 = b0 + 16;
+        if (b0 >= 0 && b1 <= rowbytes) *(uint4*)(dp0 + b0) = __builtin_bit_cast(uint4, *(const u32x4_any*)(sp0 + b0));
+        else for (int e = max(b0, 0); e < min(b1, rowbytes); ++e) dp0[e] = sp0[e];
+    }
+}
+
+// rows: false = same row (FLIP_LEFT_RIGHT), true = reversed rows as well (ROTATE_180); w % 4 == 0, rows 4-byte aligned
+__global__ __launch_bounds__(256) void mirror_rgb4_kernel(View s, View d, int rows) {
+    const int G = d.w >> 2;
+    const int64_t total = (int64_t)d.n * d.h * G;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int g = (int)(t % G);
+        const int64_t r = t / G;
+        const int y = (int)(r % d.h), f = (int)(r / d.h);
+        const u32x3_a4 v = *(const u32x3_a4*)(s.row(f, rows ? s.h - 1 - y : y) + 12 * (G - 1 - g));
+        const u32 a = v.x, b = v.y, c = v.z;
+        u32x3_a4 o;
+        o.x = __builtin_amdgcn_perm(b, c, 0x06030201u);                       // c1 c2 c3 b2
+        o.y = __builtin_amdgcn_perm(b, __builtin_amdgcn_perm(a, c, 0x00070000u), 0x04020107u);   // b3 c0 a3 b0 (via . c0 a3 .)
+        o.z = __builtin_amdgcn_perm(b, a, 0x02010005u);                       // b1 a0 a1 a2
+        *(u32x3_a4*)(d.row(f, y) + 12 * g) = o;
+    }
+}
+
 static inline unsigned grid_for(int64_t total) {
     int64_t blocks = (total + 255) / 256;
     return (unsigned)(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks));
+}
+
+static inline bool mirror_rgb4_ok(const View& s, const View& d) {
+    return d.c == 3 && (d.w & 3) == 0 &&
+           ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | ((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs) & 3) == 0;
 }
 
 } // namespace imgxf
@@ -194,6 +240,11 @@ IMGXF_API int imgxf_rot90_u8(const imgxf_view* src, const imgxf_view* dst, int q
         return IMGXF_ERR_SHAPE;
     if (empty_view(dst)) return IMGXF_OK;
     const View d = make_view(dst);
+    if (quarter_turns_ccw == 2 && mirror_rgb4_ok(make_view(src), d)) {
+        hipLaunchKernelGGL(mirror_rgb4_kernel, dim3(grid_for((int64_t)d.n * d.h * (d.w >> 2))), dim3(256), 0, (hipStream_t)stream,
+                           make_view(src), d, 1);
+        return launch_status();
+    }
     hipLaunchKernelGGL(rot90_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0,
                        (hipStream_t)stream, make_view(src), d, quarter_turns_ccw);
     return launch_status();
@@ -205,8 +256,17 @@ IMGXF_API int imgxf_flip_u8(const imgxf_view* src, const imgxf_view* dst, int mo
     if (mode < 0 || mode > 1) return IMGXF_ERR_ARG;
     if (!same_geometry(src, dst)) return IMGXF_ERR_SHAPE;
     if (empty_view(dst)) return IMGXF_OK;
-    const View d = make_view(dst);
+    const View d = make_view(dst), s = make_view(src);
+    if (mode == 1) {
+        hipLaunchKernelGGL(flip_rows_kernel, dim3(grid_for((int64_t)d.n * d.h * ((d.rowbytes() + 30) >> 4))), dim3(256), 0,
+                           (hipStream_t)stream, s, d);
+        return launch_status();
+    }
+    if (mirror_rgb4_ok(s, d)) {
+        hipLaunchKernelGGL(mirror_rgb4_kernel, dim3(grid_for((int64_t)d.n * d.h * (d.w >> 2))), dim3(256), 0, (hipStream_t)stream, s, d, 0);
+        return launch_status();
+    }
     hipLaunchKernelGGL(flip_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0,
-                       (hipStream_t)stream, make_view(src), d, mode);
+                       (hipStream_t)stream, s, d, mode);
     return launch_status();
 }
