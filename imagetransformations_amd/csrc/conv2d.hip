@@ -137,6 +137,73 @@ __global__ __launch_bounds__(256) void filter3x3_kernel(View s, View d, K9 K) {
     }
 }
 
+// 16 output bytes per lane (16-byte aligned rows): per source row one aligned 16-byte load plus the dword on
+// either side; every source byte is converted once (16 + 2C conversions per row instead of 48) and the three taps
+// of output byte i are elements i, i + C, i + 2C of that row's float window.  Same float32 operation order as
+// filter3x3_kernel (Filter.c); the frame's first / last row and the first / last chunk of a row (image border
+// pixels are copies) take the per-byte code.
+template <int C>
+__global__ __launch_bounds__(256) void filter3x3_rows16_kernel(View s, View d, K9 K) {
+    const int rowbytes = s.w * C;
+    const int nch = (rowbytes + 15) >> 4;
+    const int64_t total = (int64_t)s.n * s.h * nch;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(t % nch);
+        const int64_t r = t / nch;
+        const int y = (int)(r % s.h), f = (int)(r / s.h);
+        const int b0 = ck << 4;
+        const u8* r0 = s.row(f, y);
+        u8* dp = d.row(f, y);
+        const bool inner_row = y > 0 && y < s.h - 1 && s.w >= 3;
+        if (inner_row && ck > 0 && b0 + 16 + 4 <= rowbytes) {
+            float ss[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ss[i] = K.off;
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {                      // Filter.c: in1 = row below (y+1), in0 = row, in_1 = row above
+                const u8* rp = rr == 0 ? s.row(f, y + 1) : (rr == 1 ? r0 : s.row(f, y - 1));
+                const uint4 cv = *(const uint4*)(rp + b0);
+                const u32 lv = *(const u32*)(rp + b0 - 4), rv = *(const u32*)(rp + b0 + 16);
+                float w[16 + 2 * C];
+#pragma unroll
+                for (int j = 0; j < C; ++j) w[j] = (float)((lv >> (8 * (4 - C + j))) & 0xffu);
+                const u32 cw[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[C + j] = (float)((cw[j >> 2] >> (8 * (j & 3))) & 0xffu);
+#pragma unroll
+                for (int j = 0; j < C; ++j) w[C + 16 + j] = (float)((rv >> (8 * j)) & 0xffu);
+                const float k0 = K.k[3 * rr], k1 = K.k[3 * rr + 1], k2 = K.k[3 * rr + 2];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ss[i] += (w[i] * k0 + w[i + C] * k1) + w[i + 2 * C] * k2;
+            }
+            u32 o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = ss[i];
+                const u32 q = v <= 0.0f ? 0u : (v >= 255.0f ? 255u : (u32)(int)v);
+                o[i >> 2] |= q << (8 * (i & 3));
+            }
+            *(uint4*)(dp + b0) = make_uint4(o[0], o[1], o[2], o[3]);
+            continue;
+        }
+        const u8* rm = inner_row ? s.row(f, y - 1) : r0;
+        const u8* rp = inner_row ? s.row(f, y + 1) : r0;
+        for (int e = 0; e < 16; ++e) {
+            const int b = b0 + e;
+            if (b >= rowbytes) break;
+            u8 v = r0[b];
+            if (inner_row && b >= C && b < rowbytes - C) {
+                float a = K.off;
+                a += ((float)rp[b - C] * K.k[0] + (float)rp[b] * K.k[1]) + (float)rp[b + C] * K.k[2];
+                a += ((float)r0[b - C] * K.k[3] + (float)r0[b] * K.k[4]) + (float)r0[b + C] * K.k[5];
+                a += ((float)rm[b - C] * K.k[6] + (float)rm[b] * K.k[7]) + (float)rm[b + C] * K.k[8];
+                v = a <= 0.0f ? (u8)0 : (a >= 255.0f ? (u8)255 : (u8)(int)a);
+            }
+            dp[b] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // libImaging BoxBlur.c (ImageFilter.BoxBlur / GaussianBlur, TransformationPool.defocus_blur,
 // cifar_image_transformations.py:72-77).  One pass = ImagingLineBoxBlur: exact uint32
@@ -245,6 +312,18 @@ IMGXF_API int imgxf_filter3x3_u8(const imgxf_view* src, const imgxf_view* dst, c
     for (int i = 0; i < 9; ++i) K.k[i] = kernel9[i] / scale;      // FLOAT32 division, as _imaging.c does
     K.off = offset + 0.5f;
     const View s = make_view(src), d = make_view(dst);
+    if (((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | ((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs) & 15) == 0 &&
+        s.rowbytes() >= 48 && !getenv("IMGXF_FILTER3X3_BYTES")) {
+        const int64_t total16 = (int64_t)s.n * s.h * ((s.rowbytes() + 15) >> 4);
+        int64_t blocks16 = (total16 + 255) / 256;
+        if (blocks16 > 32768) blocks16 = 32768;
+        switch (s.c) {
+            case 1: hipLaunchKernelGGL((filter3x3_rows16_kernel<1>), dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, s, d, K); return launch_status();
+            case 3: hipLaunchKernelGGL((filter3x3_rows16_kernel<3>), dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, s, d, K); return launch_status();
+            case 4: hipLaunchKernelGGL((filter3x3_rows16_kernel<4>), dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, s, d, K); return launch_status();
+            default: break;
+        }
+    }
     const int64_t total = (int64_t)s.n * s.h * ((s.rowbytes() + 3) >> 2);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
