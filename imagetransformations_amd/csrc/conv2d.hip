@@ -8,6 +8,7 @@
 // benchmark variant), exact int32 gradients.
 #include "sobel_march.inc"
 #include <string.h>
+#include <algorithm>
 #include <stdlib.h>
 #include <math.h>
 
@@ -233,6 +234,110 @@ __global__ __launch_bounds__(256) void box_pass_kernel(View s, View d, int radiu
     }
 }
 
+// Wide-lane box passes (16-byte aligned rows, radius <= BOX_RMAX): 16 output bytes per lane, whole-dword loads.
+//   vertical:   the 2r+3 source rows of the lane's 16-byte column block are summed as packed 16-bit pairs
+//               (even / odd bytes of every dword; 13 x 255 fits 16 bits), far rows separately;
+//   horizontal: the lane's window (16 + 2 C (r+1) bytes, three aligned 16-byte loads) is unpacked once and the
+//               window sums of outputs i, i+C, i+2C ... follow each other by one add and one subtract.
+// Same integers as box_pass_kernel: out = (acc * ww + far * fw + 2^23) >> 24 in uint32.
+constexpr int BOX_RMAX = 4;
+
+__global__ __launch_bounds__(256) void box_v16_kernel(View s, View d, int radius, u32 ww, u32 fw) {
+    const int nch = (int)(s.rowbytes() >> 4);
+    const int64_t total = (int64_t)s.n * s.h * nch;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(t % nch);
+        const int64_t r = t / nch;
+        const int y = (int)(r % s.h), f = (int)(r / s.h);
+        u32 ae[4] = {0u, 0u, 0u, 0u}, ao[4] = {0u, 0u, 0u, 0u};          // even / odd bytes as 16-bit pairs
+        for (int i = -radius; i <= radius; ++i) {
+            const uint4 v = *(const uint4*)(s.row(f, clampi_(y + i, 0, s.h - 1)) + (ck << 4));
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ae[q] += w[q] & 0x00ff00ffu; ao[q] += (w[q] >> 8) & 0x00ff00ffu; }
+        }
+        const uint4 va = *(const uint4*)(s.row(f, clampi_(y - radius - 1, 0, s.h - 1)) + (ck << 4));
+        const uint4 vb = *(const uint4*)(s.row(f, clampi_(y + radius + 1, 0, s.h - 1)) + (ck << 4));
+        const u32 wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+        u32 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 fe = (wa[q] & 0x00ff00ffu) + (wb[q] & 0x00ff00ffu), fo = ((wa[q] >> 8) & 0x00ff00ffu) + ((wb[q] >> 8) & 0x00ff00ffu);
+            const u32 b0 = ((ae[q] & 0xffffu) * ww + (fe & 0xffffu) * fw + (1u << 23)) >> 24;
+            const u32 b1 = ((ao[q] & 0xffffu) * ww + (fo & 0xffffu) * fw + (1u << 23)) >> 24;
+            const u32 b2 = ((ae[q] >> 16) * ww + (fe >> 16) * fw + (1u << 23)) >> 24;
+            const u32 b3 = ((ao[q] >> 16) * ww + (fo >> 16) * fw + (1u << 23)) >> 24;
+            o[q] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+        *(uint4*)(d.row(f, y) + (ck << 4)) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int C, int R>
+__global__ __launch_bounds__(256) void box_h16_kernel(View s, View d, u32 ww, u32 fw) {
+    constexpr int HALO = C * (R + 1);                        // <= 16 (host)
+    const int rowbytes = s.w * C;
+    const int nch = (rowbytes + 15) >> 4;
+    const int64_t total = (int64_t)s.n * s.h * nch;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(t % nch);
+        const int64_t r = t / nch;
+        const int y = (int)(r % s.h), f = (int)(r / s.h);
+        const int b0 = ck << 4;
+        const u8* rp = s.row(f, y);
+        u8* dp = d.row(f, y);
+        if (ck > 0 && b0 + 32 <= rowbytes) {                 // the three 16-byte blocks around b0 lie inside the row
+            const uint4 vl = *(const uint4*)(rp + b0 - 16), vc = *(const uint4*)(rp + b0), vr = *(const uint4*)(rp + b0 + 16);
+            const u32 src[12] = {vl.x, vl.y, vl.z, vl.w, vc.x, vc.y, vc.z, vc.w, vr.x, vr.y, vr.z, vr.w};
+            u32 w[16 + 2 * HALO];                            // w[j] = byte b0 - HALO + j
+#pragma unroll
+            for (int j = 0; j < 16 + 2 * HALO; ++j) {
+                const int p = 16 - HALO + j;
+                w[j] = (src[p >> 2] >> (8 * (p & 3))) & 0xffu;
+            }
+            u32 o[4] = {0u, 0u, 0u, 0u};
+            u32 acc[C];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ph = i % C;
+                if (i < C) {
+                    u32 a = 0;
+#pragma unroll
+                    for (int k = -R; k <= R; ++k) a += w[HALO + i + C * k];
+                    acc[ph] = a;
+                } else {
+                    acc[ph] += w[HALO + i + C * R] - w[HALO + i - C * (R + 1)];
+                }
+                const u32 far = w[HALO + i - C * (R + 1)] + w[HALO + i + C * (R + 1)];
+                o[i >> 2] |= ((acc[ph] * ww + far * fw + (1u << 23)) >> 24) << (8 * (i & 3));
+            }
+            *(uint4*)(dp + b0) = make_uint4(o[0], o[1], o[2], o[3]);
+            continue;
+        }
+        for (int e = 0; e < 16; ++e) {                       // row ends: replicated edge pixels, per byte
+            const int b = b0 + e;
+            if (b >= rowbytes) break;
+            const int x = b / C, ch = b - x * C;
+            u32 a = 0;
+            for (int i = -R; i <= R; ++i) a += rp[clampi_(x + i, 0, s.w - 1) * C + ch];
+            const u32 far = (u32)rp[clampi_(x - R - 1, 0, s.w - 1) * C + ch] + (u32)rp[clampi_(x + R + 1, 0, s.w - 1) * C + ch];
+            dp[b] = (u8)((a * ww + far * fw + (1u << 23)) >> 24);
+        }
+    }
+}
+
+template <int C>
+static bool launch_box_h16(const View& s, const View& d, int radius, u32 ww, u32 fw, unsigned blocks, hipStream_t st) {
+    switch (radius) {
+        case 0: hipLaunchKernelGGL((box_h16_kernel<C, 0>), dim3(blocks), dim3(256), 0, st, s, d, ww, fw); return true;
+        case 1: hipLaunchKernelGGL((box_h16_kernel<C, 1>), dim3(blocks), dim3(256), 0, st, s, d, ww, fw); return true;
+        case 2: hipLaunchKernelGGL((box_h16_kernel<C, 2>), dim3(blocks), dim3(256), 0, st, s, d, ww, fw); return true;
+        case 3: hipLaunchKernelGGL((box_h16_kernel<C, 3>), dim3(blocks), dim3(256), 0, st, s, d, ww, fw); return true;
+        case 4: if (C * 5 <= 16) { hipLaunchKernelGGL((box_h16_kernel<C, (C * 5 <= 16 ? 4 : 0)>), dim3(blocks), dim3(256), 0, st, s, d, ww, fw); return true; } return false;
+        default: return false;
+    }
+}
+
 } // namespace imgxf
 
 using namespace imgxf;
@@ -285,7 +390,19 @@ IMGXF_API int imgxf_box_blur_u8(const imgxf_view* src, const imgxf_view* dst, fl
             // the last pass must land in dst: alternate so that parity works out
             const bool to_dst = ((total_passes - 1 - done) & 1) == 0;
             const View out = to_dst ? d : ws;
-            hipLaunchKernelGGL(box_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur, out, radius, ww, fw, axis);
+            // wide-lane kernels for 16-byte aligned images and the radii GaussianBlur produces (radius <= 4)
+            const bool al16 = ((((uintptr_t)cur.p) | (uintptr_t)cur.rs | (uintptr_t)cur.fs | ((uintptr_t)out.p) | (uintptr_t)out.rs | (uintptr_t)out.fs) & 15) == 0 &&
+                              s.rowbytes() % 16 == 0 && s.rowbytes() >= 48 && !getenv("IMGXF_BOX_BYTES");
+            const unsigned b16 = (unsigned)std::min<int64_t>(32768, ((int64_t)s.n * s.h * (s.rowbytes() >> 4) + 255) / 256);
+            bool launched = false;
+            if (al16 && radius <= BOX_RMAX) {
+                if (axis == 1) { hipLaunchKernelGGL(box_v16_kernel, dim3(b16), dim3(256), 0, st, cur, out, radius, ww, fw); launched = true; }
+                else if (s.c == 1) launched = launch_box_h16<1>(cur, out, radius, ww, fw, b16, st);
+                else if (s.c == 3) launched = launch_box_h16<3>(cur, out, radius, ww, fw, b16, st);
+                else if (s.c == 4 && radius <= 3) launched = launch_box_h16<4>(cur, out, radius, ww, fw, b16, st);
+            }
+            if (!launched)
+                hipLaunchKernelGGL(box_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur, out, radius, ww, fw, axis);
             cur = out;
             ++done;
         }
