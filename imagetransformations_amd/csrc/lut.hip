@@ -133,7 +133,11 @@ IMGXF_API int imgxf_channel_histogram_u8(const imgxf_view* src, uint32_t* hist, 
     if (empty_view(src)) return IMGXF_OK;
     const View s = make_view(src);
     if (s.n > 65535) return IMGXF_ERR_SHAPE;
-    hipLaunchKernelGGL(chist_kernel, dim3(blocks_for((int64_t)s.h * s.rowbytes() / 16), (unsigned)s.n), dim3(256), 0, st, s, hist);
+    // (c * 256 global atomics per workgroup: a few thousand workgroups per launch, not per frame)
+    unsigned hb = blocks_for((int64_t)s.h * s.rowbytes() / 16);
+    const unsigned hcap = (unsigned)(4096 / s.n < 32 ? 32 : (4096 / s.n > 512 ? 512 : 4096 / s.n));
+    if (hb > hcap) hb = hcap;
+    hipLaunchKernelGGL(chist_kernel, dim3(hb, (unsigned)s.n), dim3(256), 0, st, s, hist);
     return launch_status();
 }
 

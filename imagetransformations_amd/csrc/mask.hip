@@ -5,6 +5,7 @@
 //   binary_dilation(mask, iterations=k) with the 4-connected cross and border 0, which for
 //   this structuring element equals "some set pixel within L1 distance k".
 #include "imgxf_common.h"
+#include <algorithm>
 #include <math.h>
 #include <stdlib.h>
 
@@ -228,8 +229,11 @@ IMGXF_API int imgxf_histogram_u8(const imgxf_view* src, uint32_t* hist, void* st
     if (e != hipSuccess) return (int)e;
     if (empty_view(src)) return IMGXF_OK;
     const View s = make_view(src);
+    // every workgroup ends with 256 global atomics, one per bin: with ~1000 workgroups per frame those
+    // same-address atomics, not the reads, set the time.  A few thousand workgroups per launch fill the chip.
     int64_t bx = ((int64_t)s.h * s.w + 256 * 16 - 1) / (256 * 16);
-    if (bx > 1024) bx = 1024;
+    const int64_t cap = std::max<int64_t>(32, std::min<int64_t>(512, 4096 / s.n));
+    if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)bx, (unsigned)s.n), dim3(256), 0, st, s, hist);
     return launch_status();
