@@ -113,6 +113,43 @@ __global__ __launch_bounds__(256) void rot90_kernel(View s, View d, int turns) {
     }
 }
 
+// Quarter turns through a 32 x 32 pixel LDS tile: the source tile is read along its rows and the destination
+// tile written along its rows (the per-pixel kernel above strides one of the two sides by a whole image row per
+// lane).  Pixels sit in LDS as dwords at pitch 33, so the transposed read is conflict free.
+template <int C>
+__global__ __launch_bounds__(256) void rot90_tile_kernel(View s, View d, int turns, int ntx, int nty) {
+    __shared__ u32 tile[32][33];
+    const int bid = blockIdx.x, txb = bid % ntx, tyb = (bid / ntx) % nty, f = bid / (ntx * nty);
+    const int x0 = txb * 32, y0 = tyb * 32;                  // destination tile origin
+    const int j = threadIdx.x & 31, i0 = threadIdx.x >> 5;
+    // source tile: rows sy0 .. sy0+31, columns sx0 .. sx0+31
+    const int sy0 = turns == 1 ? x0 : s.h - 1 - x0 - 31;
+    const int sx0 = turns == 1 ? s.w - 1 - y0 - 31 : y0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = i0 + 8 * k, sy = sy0 + r, sx = sx0 + j;
+        u32 v = 0;
+        if ((u32)sy < (u32)s.h && (u32)sx < (u32)s.w) {
+            const u8* sp = s.row(f, sy) + sx * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) v |= (u32)sp[c] << (8 * c);
+        }
+        tile[r][j] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int yy = i0 + 8 * k, xx = j;
+        const int y = y0 + yy, x = x0 + xx;
+        if (y < d.h && x < d.w) {
+            const u32 v = turns == 1 ? tile[xx][31 - yy] : tile[31 - xx][yy];
+            u8* dp = d.row(f, y) + x * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) dp[c] = (u8)(v >> (8 * c));
+        }
+    }
+}
+
 // Image.transpose(FLIP_LEFT_RIGHT / FLIP_TOP_BOTTOM): dst(y,x) = src(y, w-1-x) or src(h-1-y, x)
 __global__ __launch_bounds__(256) void flip_kernel(View s, View d, int mode) {
     const int64_t total = (int64_t)d.n * d.h * d.w;
@@ -244,6 +281,20 @@ IMGXF_API int imgxf_rot90_u8(const imgxf_view* src, const imgxf_view* dst, int q
         hipLaunchKernelGGL(mirror_rgb4_kernel, dim3(grid_for((int64_t)d.n * d.h * (d.w >> 2))), dim3(256), 0, (hipStream_t)stream,
                            make_view(src), d, 1);
         return launch_status();
+    }
+    if (quarter_turns_ccw != 2 && d.c <= 4) {
+        const int ntx = (d.w + 31) / 32, nty = (d.h + 31) / 32;
+        const int64_t nb = (int64_t)ntx * nty * d.n;
+        if (nb <= 0x7fffffff) {
+            const View sv = make_view(src);
+            switch (d.c) {
+                case 1: hipLaunchKernelGGL((rot90_tile_kernel<1>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sv, d, quarter_turns_ccw, ntx, nty); break;
+                case 2: hipLaunchKernelGGL((rot90_tile_kernel<2>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sv, d, quarter_turns_ccw, ntx, nty); break;
+                case 3: hipLaunchKernelGGL((rot90_tile_kernel<3>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sv, d, quarter_turns_ccw, ntx, nty); break;
+                default: hipLaunchKernelGGL((rot90_tile_kernel<4>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sv, d, quarter_turns_ccw, ntx, nty); break;
+            }
+            return launch_status();
+        }
     }
     hipLaunchKernelGGL(rot90_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0,
                        (hipStream_t)stream, make_view(src), d, quarter_turns_ccw);

@@ -79,3 +79,18 @@ def test_mirrors_bit_exact(device, hw):
         assert torch.equal(ops.flip(view, top_bottom=True), ops.flip(ref, top_bottom=True))
     g = torch.from_numpy(np.ascontiguousarray(a[..., :1])).to(device)  # gray [N,H,W,1]: per-pixel path for left-right
     assert np.array_equal(ops.flip(g).cpu().numpy(), a[..., :1][:, :, ::-1])
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (37, 61), (270, 480), (65, 130), (1, 9), (9, 1), (33, 31)])
+def test_quarter_turns_bit_exact(device, hw):
+    """Image.transpose(ROTATE_90 / ROTATE_270) through the LDS tile, ragged sizes, batches, gray and RGBA."""
+    from imagetransformations_amd import ops
+    a = np.stack([synth(330 + i, *hw) for i in range(3)])
+    t = dev(a, device)
+    for k in (1, 3):
+        assert np.array_equal(host(ops.rot90(t, k)), np.rot90(a, k, axes=(1, 2))), k
+    rng = np.random.default_rng(1)
+    for c in (1, 4):
+        b = rng.integers(0, 256, (2, hw[0], hw[1], c), dtype=np.uint8)
+        for k in (1, 3):
+            assert np.array_equal(ops.rot90(torch.from_numpy(b).to(device), k).cpu().numpy(), np.rot90(b, k, axes=(1, 2)))
