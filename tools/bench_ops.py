@@ -55,6 +55,18 @@ if what in ("point", "all"):
     report("scale_abs", timeit(lambda: _ffi.call("imgxf_scale_abs_u8", _ffi.vp(vs), _ffi.vp(vo), 0.7, 0.0, st)), 6.0)
     report("memcpy d2d (torch copy_)", timeit(lambda: out.copy_(frames)), 6.0)
 
+if what in ("grid", "all"):
+    # the remaining transforms of the reference's grid / Pool at the facade's tensor level
+    from imagetransformations_amd.transformation import _scale_t, _translation_t
+    report("apply_translation (+50, -35)", timeit(lambda: _translation_t(frames, 50, -35), 5), 6.0)
+    for size in (5, 9, 11):
+        k = [[(1.0 / size if r == (size - 1) // 2 else 0.0) for _ in range(size)] for r in range(size)]
+        report(f"motion_blur {size} (filter2D row)", timeit(lambda: ops.conv2d(frames, k), 3), 6.0)
+    Fg = min(F, 16)
+    for sc in (1.1, 1.3, 0.9):
+        ms = timeit(lambda: _scale_t(frames[:Fg], sc), 5)
+        print(f"apply_scale x{sc} fused ({Fg} frames)        {ms:8.3f} ms  {Fg*H*W/ms/1e3:10.0f} Mpix/s  {6*Fg*H*W/ms/1e6:8.1f} GB/s  {6*Fg*H*W/ms/1e6/8000*100:5.1f}% of 8 TB/s", flush=True)
+    report("flip left-right", timeit(lambda: ops.flip(frames), 5), 6.0)
 if what in ("lanczos", "all"):
     Fs = min(F, 16)
     sub = frames[:Fs]
