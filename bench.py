@@ -402,6 +402,11 @@ def main():
         extras["apply_scale_1.1_lanczos_crop_4k"] = {"Mpix/s": round(n16 / t_sc / 1e3, 1), "frames": int(sub16.shape[0]),
                                                      "kernel": "resample_mfma_kernel (both passes on the i8 matrix cores)",
                                                      "roofline_frac": round(6.0 * n16 / (t_sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        m30 = ops.rotate_zoom_matrix(W4K, H4K, 30.0, 1.5)
+        t_bf = event_ms(lambda: ops.affine(sub, m30, (W4K, H4K), ops.BILINEAR, (0, 0, 0), precise=False), 5)
+        extras["rotate30_zoom1.5_bilinear_fp32_mode_4k"] = {     # the <= 1e-5 contract without the Pillow-exact guard / redo
+            "Mpix/s": round(npx / t_bf / 1e3, 1), "frames": int(sub.shape[0]),
+            "roofline_frac": round(AFFINE_BYTES_PER_PX * npx / (t_bf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         t_nn = event_ms(lambda: ops.rotate(sub, 22.5, ops.NEAREST, (0, 0, 0)), 5)     # apply_rotation
         extras["apply_rotation_22.5_nearest_4k"] = {"Mpix/s": round(npx / t_nn / 1e3, 1), "frames": int(sub.shape[0])}
         t_b = event_ms(lambda: ops.gaussian_blur(sub, 31, 5.0), 3)                   # apply_blur, radius 5.0 -> k = 31
