@@ -22,7 +22,19 @@ __global__ __launch_bounds__(256) void chist_kernel(View s, u32* hist) {
     const int rowbytes = s.w * C;
     const int64_t total = (int64_t)s.h * rowbytes;
     const bool vec = (rowbytes % 4 == 0) && ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 3) == 0;
-    if (vec) {
+    if (vec && (int64_t)s.h * (rowbytes >> 2) < 0x7fffffff) {
+        const u32 rowwords = (u32)rowbytes >> 2, words = (u32)s.h * rowwords;       // 32-bit index arithmetic
+        for (u32 t = blockIdx.x * 256u + threadIdx.x; t < words; t += gridDim.x * 256u) {
+            const u32 y = t / rowwords, xw = t - y * rowwords;
+            const u32 v = ((const u32*)s.row(f, (int)y))[xw];
+            int ch = (int)((xw * 4u) % (u32)C);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                atomicAdd(&hs[ch * 256 + ((v >> (8 * b)) & 0xffu)], 1u);
+                ch = ch + 1 == C ? 0 : ch + 1;
+            }
+        }
+    } else if (vec) {
         const int rowwords = rowbytes >> 2;
         const int64_t words = (int64_t)s.h * rowwords;
         for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < words; t += (int64_t)gridDim.x * 256) {
@@ -90,7 +102,32 @@ __global__ __launch_bounds__(256) void lut_apply_kernel(View s, View d, const u8
     const int rowbytes = d.w * C;
     const bool vec = (rowbytes % 4 == 0) &&
                      ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | (uintptr_t)d.p | (uintptr_t)d.rs | (uintptr_t)d.fs) & 3) == 0;
-    if (vec) {
+    const bool vec16 = (rowbytes % 16 == 0) && (int64_t)d.h * (rowbytes >> 4) < 0x7fffffff &&
+                       ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | (uintptr_t)d.p | (uintptr_t)d.rs | (uintptr_t)d.fs) & 15) == 0;
+    if (vec16) {
+        // 16 bytes per lane and 32-bit index arithmetic (the dword loop below spends more on its 64-bit
+        // division per 4 bytes than on the look-ups); the table's 64 dwords sit in 64 different banks, so the
+        // byte reads never conflict
+        const u32 nch = (u32)rowbytes >> 4, total = (u32)d.h * nch;
+        for (u32 t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+            const u32 y = t / nch, ck = t - y * nch;
+            const uint4 q = *(const uint4*)(s.row(f, (int)y) + (ck << 4));
+            const u32 w[4] = {q.x, q.y, q.z, q.w};
+            int ch = (int)((ck << 4) % (u32)C);
+            u32 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u32 acc = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    acc |= (u32)tab[ch * 256 + ((w[k] >> (8 * b)) & 0xffu)] << (8 * b);
+                    ch = ch + 1 == C ? 0 : ch + 1;
+                }
+                o[k] = acc;
+            }
+            *(uint4*)(d.row(f, (int)y) + (ck << 4)) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    } else if (vec) {
         const int rowwords = rowbytes >> 2;
         const int64_t words = (int64_t)d.h * rowwords;
         for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < words; t += (int64_t)gridDim.x * 256) {

@@ -20,7 +20,17 @@ __global__ __launch_bounds__(256) void hist_kernel(View s, u32* hist) {
     const int f = blockIdx.y;
     u32* hs = h[threadIdx.x & 7];
     const bool vec = (s.w % 4 == 0) && ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 3) == 0;
-    if (vec) {
+    if (vec && (int64_t)s.h * (s.w >> 2) < 0x7fffffff) {
+        const u32 rowwords = (u32)s.w >> 2, words = (u32)s.h * rowwords;              // 32-bit index arithmetic
+        for (u32 t = blockIdx.x * 256u + threadIdx.x; t < words; t += gridDim.x * 256u) {
+            const u32 y = t / rowwords, xw = t - y * rowwords;
+            const u32 v = ((const u32*)s.row(f, (int)y))[xw];
+            atomicAdd(&hs[v & 0xffu], 1u);
+            atomicAdd(&hs[(v >> 8) & 0xffu], 1u);
+            atomicAdd(&hs[(v >> 16) & 0xffu], 1u);
+            atomicAdd(&hs[v >> 24], 1u);
+        }
+    } else if (vec) {
         const int rowwords = s.w >> 2;
         const int64_t words = (int64_t)s.h * rowwords;
         for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < words; t += (int64_t)gridDim.x * 256) {
