@@ -2,6 +2,7 @@
 // (sepconv_march.inc) when rows are 16-byte aligned and the halo fits one block,
 // LDS-tiled general path (sepconv_tile.inc) otherwise.
 #include "sepconv_march4.inc"
+#include "sepconv_fx_mfma.inc"
 #include <stdlib.h>
 namespace imgxf {
 int sepconv_fx_c3(int R, const View& s, const View& d, const View& df, const Taps& taps,
@@ -13,6 +14,17 @@ int sepconv_fx_c3(int R, const View& s, const View& d, const View& df, const Tap
 #define IMGXF_M(r) case r: return launch_sepconv_march<3, r, true>(s, d, df, taps, st, rpw_env);
             IMGXF_M(1) IMGXF_M(2) IMGXF_M(3) IMGXF_M(4)
 #undef IMGXF_M
+            default: break;
+        }
+    }
+    // larger radii: exact integer band products on the i8 matrix cores (sepconv_fx_mfma.inc); IMGXF_FX_MFMA_MIN_R moves the threshold
+    const char* mr = getenv("IMGXF_FX_MFMA_MIN_R");
+    const int fx_min_r = mr ? atoi(mr) : 5;
+    if (!no_march && R >= fx_min_r && fx_mfma_eligible(s, d, df, 3, R, border, taps)) {
+        switch (R) {
+#define IMGXF_FM(r) case r: return launch_sepconv_fx_mfma<r>(s, d, taps, st);
+            IMGXF_FM(2) IMGXF_FM(3) IMGXF_FM(4) IMGXF_FM(5) IMGXF_FM(6) IMGXF_FM(7) IMGXF_FM(8) IMGXF_FM(9) IMGXF_FM(10) IMGXF_FM(11) IMGXF_FM(12) IMGXF_FM(13) IMGXF_FM(14) IMGXF_FM(15)
+#undef IMGXF_FM
             default: break;
         }
     }

@@ -109,3 +109,36 @@ def test_large_kernels_across_strip_geometries(device, w):
             assert np.array_equal(got[i], O.gaussian_blur_cv_fixed(frames[i], ksize, sigma)), (w, ksize, i)
             ref = O.gaussian_blur_f64(frames[i], ksize, sigma)
             assert (np.abs(f32[i].cpu().numpy() - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0)).all(), (w, ksize, i)
+
+
+@pytest.mark.parametrize("hw", [(32, 96), (37, 352), (270, 480), (65, 1280), (129, 112), (200, 2048)])
+def test_fixed_point_on_the_i8_matrix_cores(device, monkeypatch, hw):
+    """k >= 11 on aligned RGB rows: sepconv_fx_mfma.inc (integer band products), bit-exact with the oracle and
+    with the vector kernels; row chunks, batches, asymmetric integer taps."""
+    from imagetransformations_amd import ops
+    h, w = hw
+    a = np.stack([synth(600 + i, h, w) for i in range(2)])
+    t = torch.from_numpy(a).to(device)
+    for ksize, sigma in ((11, 2.0), (13, 2.0), (15, 2.5), (19, 3.0), (21, 3.5), (25, 4.0), (27, 4.5), (31, 5.0)):
+        got = ops.gaussian_blur(t, ksize, sigma, fixed_point=True)
+        for i in range(2):
+            assert np.array_equal(got[i].cpu().numpy(), O.gaussian_blur_cv_fixed(a[i], ksize, sigma)), (hw, ksize, i)
+        monkeypatch.setenv("IMGXF_FX_MFMA_MIN_R", "99")
+        assert torch.equal(got, ops.gaussian_blur(t, ksize, sigma, fixed_point=True)), (hw, ksize)
+        monkeypatch.delenv("IMGXF_FX_MFMA_MIN_R")
+    monkeypatch.setenv("IMGXF_FX_MFMA_MIN_R", "2")          # small radii through the same kernel
+    for ksize, sigma in ((5, 2.0), (7, 2.5), (9, 3.0)):
+        assert np.array_equal(ops.gaussian_blur(t, ksize, sigma, fixed_point=True)[0].cpu().numpy(),
+                              O.gaussian_blur_cv_fixed(a[0], ksize, sigma)), (hw, ksize)
+    for bpc in ("1", "3"):
+        monkeypatch.setenv("IMGXF_MFMA2_BPC", bpc)
+        assert np.array_equal(ops.gaussian_blur(t, 19, 3.0, fixed_point=True)[1].cpu().numpy(), O.gaussian_blur_cv_fixed(a[1], 19, 3.0)), bpc
+    monkeypatch.delenv("IMGXF_MFMA2_BPC")
+    monkeypatch.delenv("IMGXF_FX_MFMA_MIN_R")
+    kx = [3, 9, 20, 40, 60, 50, 35, 20, 10, 6, 3]          # asymmetric, sums to 256; ky symmetric
+    ky = [1, 4, 10, 22, 40, 102, 40, 22, 10, 4, 1]
+    got = ops.sepconv_fixed(t[0], kx, ky).cpu().numpy()
+    p = np.pad(a[0].astype(np.int64), ((5, 5), (5, 5), (0, 0)), mode="reflect")
+    hp = sum(kx[j] * p[:, j:j + w] for j in range(11))
+    vp = sum(ky[i] * hp[i:i + h] for i in range(11))
+    assert np.array_equal(got, ((vp + 32768) >> 16).astype(np.uint8))
