@@ -21,7 +21,7 @@ def _check(out, ref_f):
     assert diff.max() <= 1 and (diff == 0)[~near_tie].all()
 
 
-@pytest.mark.parametrize("hw", [(32, 32), (37, 61), (64, 352), (270, 480), (129, 1280)])
+@pytest.mark.parametrize("hw", [(32, 32), (37, 61), (64, 352), (270, 480), (129, 1280), (5, 7), (3, 3), (2, 9), (1, 1)])   # the last ones: images smaller than the kernel
 @pytest.mark.parametrize("size", [5, 7, 9, 11, 13, 15])
 def test_motion_blur_rows_every_family(device, hw, size):
     from imagetransformations_amd import ops
