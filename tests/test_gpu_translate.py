@@ -94,3 +94,17 @@ def test_quarter_turns_bit_exact(device, hw):
         b = rng.integers(0, 256, (2, hw[0], hw[1], c), dtype=np.uint8)
         for k in (1, 3):
             assert np.array_equal(ops.rot90(torch.from_numpy(b).to(device), k).cpu().numpy(), np.rot90(b, k, axes=(1, 2)))
+
+
+@pytest.mark.parametrize("m", [(1, 0, -3.5, 0, 1, 2.25), (0.5, 0, 0, 0, 0.5, 0), (2.3, 0, -10, 0, 1.7, 5), (-1, 0, 60, 0, 1, 0),
+                               (1, 0, 1000, 0, 1, 0), (1.0, 0, 0.4999, 0, 1.0, -0.5)])
+def test_axis_aligned_nearest_dword_kernel(device, m):
+    """ImagingScaleAffine (AugMix translate_x/y, zoom without rotation) with 4 pixels per lane: widths that are
+    multiples of 4, batches, fill colour; the ragged widths keep the per-pixel kernel (test_gpu_parity)."""
+    from imagetransformations_amd import ops
+    a = np.stack([synth(340 + i, 37, 64) for i in range(3)])
+    t = dev(a, device)
+    for size in [(64, 37), (128, 50), (20, 8)]:
+        got = host(ops.affine(t, m, size, ops.NEAREST, (9, 8, 7)))
+        for i in range(3):
+            assert np.array_equal(got[i], O.affine_nearest(a[i], size, [float(v) for v in m], fill=(9, 8, 7))), (m, size, i)
