@@ -1,0 +1,77 @@
+"""Soak for the kernels added in round 2 (fused matrix-core resample, matrix-core Gaussians in float and
+fixed-point mode, separable filter2D routing, translation / mirrors / quarter turns, wide-lane 3x3 and box
+filters): IMGXF_SOAK=<n> runs n further seeds of random geometries against the oracle / Pillow; the default
+suite runs 2 seeds.  Every check is bit-exact except the float filters (fp64 oracle, tie tolerance)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image, ImageFilter
+
+from oracle import imgxf_oracle as O
+from test_gpu_parity import assert_quantised_close
+
+pytestmark = pytest.mark.gpu
+SEEDS = int(os.environ.get("IMGXF_SOAK", "2"))
+
+
+def _img(rng, h, w, c=3):
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        return rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+    if kind == 1:
+        y, x = np.mgrid[0:h, 0:w]
+        return np.stack([((x * 255 // max(w - 1, 1) + y * 3 + 40 * k) % 256) for k in range(c)], -1).astype(np.uint8)
+    a = np.full((h, w, c), int(rng.integers(0, 256)), np.uint8)
+    a[rng.random((h, w)) < 0.03] = rng.integers(0, 256, c)
+    return a
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_soak_round2_kernels(device, seed):
+    from imagetransformations_amd import ops
+    from imagetransformations_amd import transformation as T
+    rng = np.random.default_rng(770000 + seed)
+    h, w = int(rng.integers(33, 240)), int(rng.integers(6, 40)) * 16
+    a = _img(rng, h, w)
+    t = torch.from_numpy(a).to(device)
+    # fused resample: any filter, both directions, optional crop window
+    sx, sy = float(rng.uniform(0.62, 2.2)), float(rng.uniform(0.62, 2.2))
+    nw, nh = max(1, int(w * sx)), max(1, int(h * sy))
+    flt = int(rng.choice([1, 1, 2, 3, 4, 5]))
+    ref = O.resize(a, (nw, nh), flt)
+    assert np.array_equal(ops.resize(t, (nw, nh), flt).cpu().numpy(), ref), ("resize", h, w, nw, nh, flt)
+    if nw > 8 and nh > 8 and nw != w and nh != h:
+        l, tp = int(rng.integers(0, nw // 2)), int(rng.integers(0, nh // 2))
+        r, b = int(rng.integers(l + 1, nw + 1)), int(rng.integers(tp + 1, nh + 1))
+        assert np.array_equal(ops.resize_crop(t, (nw, nh), (l, tp, r, b), flt).cpu().numpy(), ref[tp:b, l:r]), ("crop", l, tp, r, b)
+    s = float(rng.choice(O.grid_values("scale")))
+    assert np.array_equal(T._scale_t(t, s).cpu().numpy(), O.apply_scale(a, s)), ("apply_scale", h, w, s)
+    # large-radius Gaussian: float definition (tolerance) and fixed-point mode (bit-exact)
+    radius = float(rng.choice([2.0, 2.5, 3.0, 3.5, 4.0, 4.5, 5.0]))
+    k = O.blur_ksize(radius)
+    out, f32 = ops.gaussian_blur(t, k, radius, return_f32=True)
+    assert_quantised_close(out.cpu().numpy(), f32.cpu().numpy(), O.gaussian_blur_f64(a, k, radius), O.saturate_u8)
+    assert np.array_equal(ops.gaussian_blur(t, k, radius, fixed_point=True).cpu().numpy(), O.gaussian_blur_cv_fixed(a, k, radius)), ("fixed", k)
+    # filter2D: motion blur rows and a random outer product
+    size = int(rng.choice([5, 7, 9, 11, 13, 15]))
+    for kern in (O.motion_blur_kernel(size), np.outer(rng.uniform(0, 0.4, int(rng.choice([1, 3, 5, 9]))), rng.uniform(0, 0.4, int(rng.choice([3, 7, 11]))))):
+        ref_f = O.conv2d_f64(a, kern)
+        got = ops.conv2d(t, np.asarray(kern).tolist()).cpu().numpy()
+        d = np.abs(got.astype(int) - O.saturate_u8(ref_f).astype(int))
+        tie = np.abs(ref_f - np.floor(ref_f) - 0.5) < 1e-4
+        assert d.max() <= 1 and (d == 0)[~tie].all(), ("filter2D", kern.shape)
+    # integer geometry
+    tx, ty = float(rng.uniform(-1.2 * w, 1.2 * w)), float(rng.uniform(-1.2 * h, 1.2 * h))
+    assert np.array_equal(T._translation_t(t, tx, ty).cpu().numpy(), O.apply_translation(a, tx, ty)), ("translation", tx, ty)
+    assert np.array_equal(ops.flip(t).cpu().numpy(), a[:, ::-1]) and np.array_equal(ops.flip(t, True).cpu().numpy(), a[::-1])
+    for q in (1, 2, 3):
+        assert np.array_equal(ops.rot90(t, q).cpu().numpy(), np.rot90(a, q)), ("rot90", q)
+    # Pillow's own filters
+    img = Image.fromarray(a)
+    assert np.array_equal(ops.filter3x3(t, ops.SMOOTH_KERNEL, 13).cpu().numpy(), np.asarray(img.filter(ImageFilter.SMOOTH)))
+    rad = float(rng.choice([0.5, 1.0, 2.0, 3.0, 4.0, 5.0, 6.5]))
+    assert np.array_equal(ops.gaussian_blur_pil(t, rad).cpu().numpy(), np.asarray(img.filter(ImageFilter.GaussianBlur(rad)))), ("defocus", rad)
+    brad = float(rng.uniform(0.2, 5.0))
+    assert np.array_equal(ops.box_blur(t, brad).cpu().numpy(), np.asarray(img.filter(ImageFilter.BoxBlur(brad)))), ("box", brad)
