@@ -760,7 +760,9 @@ IMGXF_API int imgxf_resize_lanczos_u8(const imgxf_lanczos_plan* p, const imgxf_v
 // does this call run the fused matrix-core kernel (no intermediate)?
 static bool resample_runs_fused(const imgxf_lanczos_plan* p, const imgxf_view* src, const imgxf_view* dst) {
     if (!p->need_h || !p->need_v || !src || !dst) return false;
-    if (getenv("IMGXF_LANCZOS_SLOW") || getenv("IMGXF_RESAMPLE_NO_MFMA")) return false;
+    // the knobs that pick a variant of the two-pass kernels imply the two-pass path
+    if (getenv("IMGXF_LANCZOS_SLOW") || getenv("IMGXF_RESAMPLE_NO_MFMA") || getenv("IMGXF_LANCZOS_NO_LDS") || getenv("IMGXF_LANCZOS_NO_V4"))
+        return false;
     return rs_mf_ok(p, make_view(src), make_view(dst));
 }
 
