@@ -60,7 +60,8 @@ def test_fuzz_aligned_fast_paths(device, seed):
     if h > k and w > k:
         out, f32 = ops.gaussian_blur(t, k, r, return_f32=True)
         ref = O.gaussian_blur_f64(a, k, r)
-        assert (np.abs(host(f32) - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0)).all(), ("gauss", h, w, k)
+        mfma = 2.0 ** -22 * float(a.max()) if k >= 13 else 0.0      # matrix-core kernels: error relative to the brightest pixel (test_gpu_parity.MFMA_ABS)
+        assert (np.abs(host(f32) - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0) + mfma).all(), ("gauss", h, w, k)
     # mask stage
     g = a[..., 0]
     mask = g > np.percentile(g, 90)
