@@ -60,7 +60,7 @@ def test_fuzz_aligned_fast_paths(device, seed):
     if h > k and w > k:
         out, f32 = ops.gaussian_blur(t, k, r, return_f32=True)
         ref = O.gaussian_blur_f64(a, k, r)
-        mfma = 2.0 ** -22 * float(a.max()) if k >= 13 else 0.0      # matrix-core kernels: error relative to the brightest pixel (test_gpu_parity.MFMA_ABS)
+        mfma = 0.0      # (the matrix-core kernels hold the plain tolerance since their bytes go in as b * 2^-22: DESIGN section 4)
         assert (np.abs(host(f32) - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0) + mfma).all(), ("gauss", h, w, k)
     # mask stage
     g = a[..., 0]
