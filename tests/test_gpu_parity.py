@@ -28,7 +28,7 @@ def host(t):
 MFMA_ABS = 0.0             # (was 2^-22 x the largest pixel value until the denormal-alignment loss was understood and cut, see below)
 
 
-def assert_quantised_close(got_u8, got_f32, ref_f64, quantise, rel=1e-5, abs_term=0.0):
+def assert_quantised_close(got_u8, got_f32, ref_f64, quantise, rel=1e-5, abs_term=0.0, max_tie_fraction=1e-3):
     """got_f32 within rel of ref; got_u8 == quantise(ref) except at boundary ties.
 
     abs_term: additional absolute tolerance (0 everywhere today).  It was MFMA_ABS * image.max() for the f16
@@ -47,7 +47,7 @@ def assert_quantised_close(got_u8, got_f32, ref_f64, quantise, rel=1e-5, abs_ter
         # every mismatch must be explained by the tolerance: quantising ref +- tol flips it
         lo, hi = quantise(ref - tol), quantise(ref + tol)
         assert ((got_u8 == lo) | (got_u8 == hi))[bad].all()
-        assert bad.mean() < 1e-3
+        assert bad.mean() < max_tie_fraction      # (a sanity bound: structured images put whole classes of pixels on a tie)
 
 
 # ------------------------------------------------------------------ a1 Gaussian
