@@ -107,3 +107,36 @@ def test_soak_batched_kernels(device, seed):
     got = ops.affine(t, ms, (nw, h), ops.BICUBIC, (255, 255, 255), precise=True).cpu().numpy()
     for i in (0, n - 1):
         assert np.array_equal(got[i], O.apply_shear(a[i], sh)), ("shear", sh, i)
+
+
+@pytest.mark.parametrize("seed", range(max(1, SEEDS // 100)))
+def test_soak_full_size_equivalences(device, seed, monkeypatch):
+    """4K / 1080p frames: the matrix-core kernels against the kernels they replaced (no oracle at this size):
+    fused resample == two-pass, fixed-point Gaussian on the i8 cores == vector kernels, float Gaussian within a
+    rounding tie of the vector kernels, translation == fill + paste."""
+    from imagetransformations_amd import ops
+    from imagetransformations_amd import transformation as T
+    rng = np.random.default_rng(990000 + seed)
+    h, w = ((2160, 3840), (1080, 1920))[int(rng.integers(0, 2))]
+    g = torch.Generator(device="cpu").manual_seed(int(rng.integers(0, 1 << 30)))
+    t = torch.randint(0, 256, (2, h, w, 3), dtype=torch.uint8, generator=g).to(device)
+    if seed % 2: t[:, : h // 3] = int(rng.integers(0, 4))                     # a dark band: small pixel values
+    s = float(rng.uniform(0.7, 1.8))
+    fused = T._scale_t(t, s)
+    monkeypatch.setenv("IMGXF_RESAMPLE_NO_MFMA", "1")
+    assert torch.equal(fused, T._scale_t(t, s)), ("scale", h, w, s)
+    monkeypatch.delenv("IMGXF_RESAMPLE_NO_MFMA")
+    radius = float(rng.choice([2.0, 2.5, 3.0, 3.5, 4.0, 4.5, 5.0]))
+    k = O.blur_ksize(radius)
+    fx = ops.gaussian_blur(t, k, radius, fixed_point=True)
+    fl = ops.gaussian_blur(t, k, radius)
+    monkeypatch.setenv("IMGXF_FX_MFMA_MIN_R", "99"); monkeypatch.setenv("IMGXF_MFMA_MIN_R", "99")
+    assert torch.equal(fx, ops.gaussian_blur(t, k, radius, fixed_point=True)), ("fixed", k)
+    d = (fl.int() - ops.gaussian_blur(t, k, radius).int()).abs()
+    assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-3, ("float", k)
+    monkeypatch.delenv("IMGXF_FX_MFMA_MIN_R"); monkeypatch.delenv("IMGXF_MFMA_MIN_R")
+    tx, ty = int(rng.integers(-w, w)), int(rng.integers(-h, h))
+    ref = ops.new(t, h, w, (0, 0, 0))
+    cl, ct, cr, cb = max(0, -tx), max(0, -ty), min(w, w - tx), min(h, h - ty)
+    if cl < cr and ct < cb: ops.copy_rect(t, ref, cl, ct, max(0, tx), max(0, ty), cr - cl, cb - ct)
+    assert torch.equal(T._translation_t(t, tx, ty), ref), ("translation", tx, ty)
