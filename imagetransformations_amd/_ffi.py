@@ -93,9 +93,18 @@ SIGNATURES = {
     "imgxf_to_tensor_f32": [_VP, C.c_void_p, _F, _F, C.c_void_p],
     "imgxf_perspective_bilinear_u8": [_VP, _VP, C.POINTER(C.c_float), C.c_int, C.c_void_p],
     "imgxf_histogram_u8": [_VP, C.c_void_p, C.c_void_p],
+    "imgxf_jpeg_workspace_bytes": [C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_size_t)],
+    "imgxf_jpeg_encode_u8": [_VP, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                             C.c_void_p],
     "imgxf_percentile_mask_u8": [_VP, C.c_void_p, C.c_double, _VP, C.c_void_p, C.c_void_p],
     "imgxf_dilate_cross_u8": [_VP, _VP, C.c_int, C.c_void_p],
 }
+
+
+class JpegTables(C.Structure):
+    """struct imgxf_jpeg_tables (include/imgxf.h)."""
+    _fields_ = [("quant", (C.c_uint16 * 64) * 2), ("dc_code", (C.c_uint16 * 16) * 2), ("dc_len", (C.c_uint8 * 16) * 2),
+                ("ac_code", (C.c_uint16 * 256) * 2), ("ac_len", (C.c_uint8 * 256) * 2)]
 
 
 def _load() -> C.CDLL:

@@ -1,0 +1,572 @@
+// Baseline JPEG writer on the device: the byte stream Pillow's `Image.save(fp, "JPEG")` (libjpeg-turbo: 4:2:0, islow
+// DCT, Annex-K Huffman tables, no restart markers) writes for an RGB image — the save step of the reference driver,
+// transformation.py:161-162.  A batch of n frames → n independent files.
+//
+//   jpeg_transform_kernel   RGB → YCbCr (16-bit fixed point) → 2×2 chroma averaging → 8×8 forward DCT → quantise;
+//                           16 MCUs (16×256 px) per workgroup staged through LDS, one thread per 8×8 block, zigzag
+//                           int16 coefficients in MCU order (6 blocks per MCU) to the workspace
+//   jpeg_entropy_kernel<0>  bits per block (DC difference + run/size symbols)          → exclusive scan = bit offsets
+//   jpeg_entropy_kernel<1>  the same walk, emitting the codes at the block's bit offset (atomic OR at shared words)
+//   jpeg_ffcount / jpeg_stuff_kernel   0xFF → 0xFF 0x00 byte stuffing (count per 32-byte chunk, scan, scatter),
+//                           header, padding of the last byte with 1-bits, EOI, file size per frame
+//
+// Integer arithmetic throughout: bit-identical to the library (tests/test_gpu_jpeg.py compares whole files).
+#include "imgxf_common.h"
+#include <string.h>
+
+namespace imgxf {
+
+constexpr int JM = 16;                       // MCUs per transform workgroup
+constexpr int JCHUNK = 32;                   // bytes per stuffing thread
+
+struct JpegQuant {                           // per coefficient (natural order): |c| → ((|c| + half) · m) >> 32
+    u32 m[2][64];                            // ceil(2^32 / 8q)
+    u32 half[2][64];                         // 4q
+};
+struct JpegHuff {                            // code | len << 16
+    u32 dc[2][16];
+    u32 ac[2][256];
+};
+struct JpegHeader {
+    u8 b[1024];
+    int len;
+};
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// jfdctint.c, one 1-D pass over eight values (FIRST: the row pass, results scaled up by 4).
+template <bool FIRST>
+__device__ __forceinline__ void fdct8(int& d0, int& d1, int& d2, int& d3, int& d4, int& d5, int& d6, int& d7) {
+    constexpr int N = FIRST ? 11 : 15;
+    const int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+    const int t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    if (FIRST) {
+        d0 = (t10 + t11) << 2;
+        d4 = (t10 - t11) << 2;
+    } else {
+        d0 = descale(t10 + t11, 2);
+        d4 = descale(t10 - t11, 2);
+    }
+    int z1 = __mul24(t12 + t13, 4433);
+    d2 = descale(z1 + __mul24(t13, 6270), N);
+    d6 = descale(z1 - __mul24(t12, 15137), N);
+    z1 = t4 + t7;
+    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+    const int z5 = __mul24(z3 + z4, 9633);
+    const int a4 = __mul24(t4, 2446), a5 = __mul24(t5, 16819), a6 = __mul24(t6, 25172), a7 = __mul24(t7, 12299);
+    z1 = -__mul24(z1, 7373);
+    z2 = -__mul24(z2, 20995);
+    z3 = z5 - __mul24(z3, 16069);
+    z4 = z5 - __mul24(z4, 3196);
+    d7 = descale(a4 + z1 + z3, N);
+    d5 = descale(a5 + z2 + z4, N);
+    d3 = descale(a6 + z2 + z3, N);
+    d1 = descale(a7 + z1 + z4, N);
+}
+
+__device__ __forceinline__ u32 ycc_y(u32 r, u32 g, u32 b) { return (19595u * r + 38470u * g + 7471u * b + 32768u) >> 16; }
+__device__ __forceinline__ u32 ycc_cb(int r, int g, int b) { return (u32)(-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16; }
+__device__ __forceinline__ u32 ycc_cr(int r, int g, int b) { return (u32)(32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16; }
+
+constexpr int zz(int i) {
+    constexpr int t[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+                           41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
+                           15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55,
+                           62, 63};
+    return t[i];
+}
+
+// One workgroup: rows y0 .. y0+15, columns x0 .. x0+255 of frame f.  128 threads: both waves stage and convert, then
+// wave 0 transforms the 64 luminance blocks and the lower half of wave 1 the 32 chrominance blocks.
+__global__ __launch_bounds__(128) void jpeg_transform_kernel(View s, int16_t* __restrict__ coef, int64_t coef_fs, int mw,
+                                                             int bw, int bh, JpegQuant q) {
+    __shared__ __attribute__((aligned(16))) u8 rgb[16][768];
+    __shared__ __attribute__((aligned(16))) u8 yp[16][256 + 8];
+    __shared__ __attribute__((aligned(16))) u8 cp[2][8][128 + 8];
+    const int tid = threadIdx.x, f = blockIdx.z, my = blockIdx.y, mx0 = blockIdx.x * JM;
+    const int y0 = my * 16, x0 = mx0 * 16;
+    const u8* base = s.p + (int64_t)f * s.fs;
+    const bool fast = (x0 + 256 <= s.w) && (((uintptr_t)base | (uintptr_t)s.rs) & 15) == 0;
+    for (int i = tid; i < 16 * 48; i += 128) {
+        const int r = i / 48, ch = i - r * 48;
+        const u8* row = base + (int64_t)min(y0 + r, s.h - 1) * s.rs;
+        if (fast) {
+            *(uint4*)&rgb[r][ch * 16] = *(const uint4*)(row + x0 * 3 + ch * 16);
+        } else {
+            for (int b = 0; b < 16; ++b) {
+                const int o = ch * 16 + b, px = o / 3, cc = o - px * 3;
+                rgb[r][o] = row[min(x0 + px, s.w - 1) * 3 + cc];
+            }
+        }
+    }
+    __syncthreads();
+    // luminance: four pixels (three dwords) per task
+    for (int i = tid; i < 16 * 64; i += 128) {
+        const int r = i >> 6, g4 = i & 63;
+        const u32* p = (const u32*)&rgb[r][g4 * 12];
+        const u32 a = p[0], b = p[1], c = p[2];
+        const u32 y0v = ycc_y(a & 255, (a >> 8) & 255, (a >> 16) & 255);
+        const u32 y1v = ycc_y(a >> 24, b & 255, (b >> 8) & 255);
+        const u32 y2v = ycc_y((b >> 16) & 255, b >> 24, c & 255);
+        const u32 y3v = ycc_y((c >> 8) & 255, (c >> 16) & 255, c >> 24);
+        *(u32*)&yp[r][g4 * 4] = y0v | (y1v << 8) | (y2v << 16) | (y3v << 24);
+    }
+    // chrominance: two samples (4×2 pixels) per task; rows past the image repeat the last DOWNSAMPLED row
+    const int crows = (s.h + 1) >> 1;
+    for (int i = tid; i < 8 * 64; i += 128) {
+        const int j = i >> 6, g4 = i & 63;
+        const int ce = min(y0 / 2 + j, crows - 1);
+        const int ra = 2 * ce - y0, rb = min(2 * ce + 1, s.h - 1) - y0;
+        const u32* pa = (const u32*)&rgb[ra][g4 * 12];
+        const u32* pb = (const u32*)&rgb[rb][g4 * 12];
+        u32 cb[2] = {1, 2}, cr[2] = {1, 2};                      // h2v2_downsample's alternating bias
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32* p = h ? pb : pa;
+            const u32 a = p[0], b = p[1], c = p[2];
+            const int r0 = a & 255, g0 = (a >> 8) & 255, b0 = (a >> 16) & 255;
+            const int r1 = a >> 24, g1 = b & 255, b1 = (b >> 8) & 255;
+            const int r2 = (b >> 16) & 255, g2 = b >> 24, b2 = c & 255;
+            const int r3 = (c >> 8) & 255, g3 = (c >> 16) & 255, b3 = c >> 24;
+            cb[0] += ycc_cb(r0, g0, b0) + ycc_cb(r1, g1, b1);
+            cb[1] += ycc_cb(r2, g2, b2) + ycc_cb(r3, g3, b3);
+            cr[0] += ycc_cr(r0, g0, b0) + ycc_cr(r1, g1, b1);
+            cr[1] += ycc_cr(r2, g2, b2) + ycc_cr(r3, g3, b3);
+        }
+        *(uint16_t*)&cp[0][j][g4 * 2] = (uint16_t)((cb[0] >> 2) | ((cb[1] >> 2) << 8));
+        *(uint16_t*)&cp[1][j][g4 * 2] = (uint16_t)((cr[0] >> 2) | ((cr[1] >> 2) << 8));
+    }
+    __syncthreads();
+    if (tid >= 96) return;
+    const int chroma = __builtin_amdgcn_readfirstlane(tid >= 64 ? 1 : 0);
+    int ml, k;
+    const u8* origin;
+    int stride;
+    bool real;
+    if (!chroma) {
+        ml = tid >> 2;
+        k = tid & 3;
+        origin = &yp[(k >> 1) * 8][ml * 16 + (k & 1) * 8];
+        stride = 256 + 8;
+        real = (2 * my + (k >> 1) < bh) && (2 * (mx0 + ml) + (k & 1) < bw);
+    } else {
+        const int c = (tid - 64) >> 4;
+        ml = (tid - 64) & 15;
+        k = 4 + c;
+        origin = &cp[c][0][ml * 8];
+        stride = 128 + 8;
+        real = true;
+    }
+    if (mx0 + ml >= mw || !real) return;
+    int d[64];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint2 v = *(const uint2*)(origin + r * stride);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            d[r * 8 + x] = (int)((v.x >> (8 * x)) & 255) - 128;
+            d[r * 8 + 4 + x] = (int)((v.y >> (8 * x)) & 255) - 128;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        fdct8<true>(d[r * 8], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5], d[r * 8 + 6], d[r * 8 + 7]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        fdct8<false>(d[c], d[8 + c], d[16 + c], d[24 + c], d[32 + c], d[40 + c], d[48 + c], d[56 + c]);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {                                // jcdctmgr.c quantize: sign · ((|c| + 4q) / 8q)
+        const int v = d[i], sg = v >> 31;
+        const u32 a = (u32)((v ^ sg) - sg);
+        const u32 qq = __umulhi(a + q.half[chroma][i], q.m[chroma][i]);
+        d[i] = ((int)qq ^ sg) - sg;
+    }
+    uint4* out = (uint4*)(coef + (int64_t)f * coef_fs + ((int64_t)((int64_t)my * mw + mx0 + ml) * 6 + k) * 64);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        uint4 v;
+        v.x = (u32)(d[zz(g * 8 + 0)] & 0xffff) | ((u32)d[zz(g * 8 + 1)] << 16);
+        v.y = (u32)(d[zz(g * 8 + 2)] & 0xffff) | ((u32)d[zz(g * 8 + 3)] << 16);
+        v.z = (u32)(d[zz(g * 8 + 4)] & 0xffff) | ((u32)d[zz(g * 8 + 5)] << 16);
+        v.w = (u32)(d[zz(g * 8 + 6)] & 0xffff) | ((u32)d[zz(g * 8 + 7)] << 16);
+        out[g] = v;
+    }
+}
+
+// ---- entropy coding -------------------------------------------------------------------------------------------------
+
+struct JpegGeom {
+    int mw, mh, bw, bh, nblk;
+};
+
+// jccoefct.c compress_data: block k of an MCU is a dummy (zero AC, DC of the block before it) when it lies past the
+// component's last real block row / column; returns the block whose DC it carries.
+__device__ __forceinline__ int dc_source(const JpegGeom& g, int mx, int my, int k, bool& dummy) {
+    dummy = false;
+    if (k >= 4) return k;
+    const int yi = k >> 1, xi = k & 1;
+    const bool rowok = 2 * my + yi < g.bh, colok = 2 * mx + xi < g.bw;
+    if (rowok && colok) return k;
+    dummy = true;
+    if (!rowok) return (2 * mx + 1 < g.bw) ? 1 : 0;          // a whole dummy row: DC of the top row's last real block
+    return k - 1;                                              // right edge: the block to its left
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void jpeg_entropy_kernel(const int16_t* __restrict__ coef, int64_t coef_fs, u32* __restrict__ lens,
+                                                           int64_t lens_fs, u32* __restrict__ stream, int64_t stream_fs_words,
+                                                           const u32* __restrict__ total_bits, JpegGeom g, JpegHuff hf) {
+    __shared__ u32 sdc[2][16];
+    __shared__ u32 sac[2][256];
+    for (int i = threadIdx.x; i < 32; i += 256) sdc[i >> 4][i & 15] = hf.dc[i >> 4][i & 15];
+    for (int i = threadIdx.x; i < 512; i += 256) sac[i >> 8][i & 255] = hf.ac[i >> 8][i & 255];
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (j >= g.nblk) return;
+    const int mcu = j / 6, k = j - mcu * 6, my = mcu / g.mw, mx = mcu - my * g.mw;
+    const int16_t* cf = coef + (int64_t)f * coef_fs;
+    bool dummy, pd;
+    const int src = dc_source(g, mx, my, k, dummy);
+    const int dcv = cf[((int64_t)mcu * 6 + src) * 64];
+    int pred = 0;
+    if (k >= 4) {
+        if (mcu > 0) pred = cf[((int64_t)(mcu - 1) * 6 + k) * 64];
+    } else if (k > 0) {
+        pred = cf[((int64_t)mcu * 6 + dc_source(g, mx, my, k - 1, pd)) * 64];
+    } else if (mcu > 0) {
+        const int pm = mcu - 1, pmy = pm / g.mw, pmx = pm - pmy * g.mw;
+        pred = cf[((int64_t)pm * 6 + dc_source(g, pmx, pmy, 3, pd)) * 64];
+    }
+    const int t = k >= 4 ? 1 : 0;
+    u32 bits = 0;
+    unsigned long long acc = 0;
+    u32 nb = 0;
+    u32* wp = nullptr;
+    bool first = true;
+    if (EMIT) {
+        if (((unsigned long long)total_bits[f] + 31) / 32 > (unsigned long long)stream_fs_words) return;   // reported by jpeg_stuff_kernel
+        const u32 off = lens[(int64_t)f * lens_fs + j];
+        nb = off & 31;
+        wp = stream + (int64_t)f * stream_fs_words + (off >> 5);
+    }
+    auto put = [&](u32 code, u32 len) {
+        if (EMIT) {
+            acc |= (unsigned long long)code << (64 - nb - len);
+            nb += len;
+            if (nb >= 32) {
+                if (first) atomicOr(wp, (u32)(acc >> 32));
+                else *wp = (u32)(acc >> 32);
+                first = false;
+                ++wp;
+                acc <<= 32;
+                nb -= 32;
+            }
+        } else {
+            bits += len;
+        }
+    };
+    {
+        const int diff = dcv - pred, sg = diff >> 31;
+        const u32 ad = (u32)((diff ^ sg) - sg);
+        const u32 cat = ad ? 32 - __builtin_clz(ad) : 0;
+        const u32 e = sdc[t][cat];
+        put(((e & 0xffff) << cat) | ((u32)(diff + sg) & ((1u << cat) - 1)), (e >> 16) + cat);
+    }
+    if (!dummy) {
+        const uint4* blk = (const uint4*)(cf + ((int64_t)mcu * 6 + k) * 64);
+        const u32 zrl = sac[t][0xF0];
+        u32 run = 0;
+        for (int gidx = 0; gidx < 8; ++gidx) {
+            const uint4 v = blk[gidx];
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+                if (gidx == 0 && e8 == 0) continue;
+                const int c = (int)(int16_t)(w[e8 >> 1] >> (16 * (e8 & 1)));
+                if (c == 0) {
+                    ++run;
+                    continue;
+                }
+                for (u32 z = run >> 4; z > 0; --z) put(zrl & 0xffff, zrl >> 16);
+                const int sg = c >> 31;
+                const u32 cat = 32 - __builtin_clz((c ^ sg) - sg);
+                const u32 e = sac[t][((run & 15) << 4) | cat];
+                put(((e & 0xffff) << cat) | ((u32)(c + sg) & ((1u << cat) - 1)), (e >> 16) + cat);
+                run = 0;
+            }
+        }
+        if (run) {
+            const u32 e = sac[t][0];
+            put(e & 0xffff, e >> 16);
+        }
+    } else {
+        const u32 e = sac[t][0];
+        put(e & 0xffff, e >> 16);
+    }
+    if (EMIT) {
+        if (nb) atomicOr(wp, (u32)(acc >> 32));
+    } else {
+        lens[(int64_t)f * lens_fs + j] = bits;
+    }
+}
+
+// ---- exclusive scan of u32 rows (in place), 1024 elements per workgroup ---------------------------------------------
+
+__device__ __forceinline__ u32 wg_exclusive_scan(u32 v, u32* total) {          // 256 threads
+    __shared__ u32 wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    u32 basev = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < wv) basev += wsum[i];
+        tot += wsum[i];
+    }
+    *total = tot;
+    return basev + x - v;
+}
+
+__global__ __launch_bounds__(256) void scan_partials_kernel(const u32* __restrict__ data, int64_t fs, int len, u32* __restrict__ part,
+                                                            int nparts) {
+    const int f = blockIdx.y;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const u32* p = data + (int64_t)f * fs;
+    u32 s = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += (i0 + e < len) ? p[i0 + e] : 0u;
+    u32 tot;
+    wg_exclusive_scan(s, &tot);
+    if (threadIdx.x == 0) part[(int64_t)f * nparts + blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void scan_spine_kernel(u32* __restrict__ part, int nparts, u32* __restrict__ totals) {
+    const int f = blockIdx.x;
+    u32* p = part + (int64_t)f * nparts;
+    u32 carry = 0;
+    for (int b = 0; b < nparts; b += 256) {
+        const int i = b + threadIdx.x;
+        const u32 v = i < nparts ? p[i] : 0u;
+        u32 tot;
+        const u32 ex = wg_exclusive_scan(v, &tot);
+        if (i < nparts) p[i] = carry + ex;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[f] = carry;
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(u32* __restrict__ data, int64_t fs, int len, const u32* __restrict__ part,
+                                                         int nparts) {
+    const int f = blockIdx.y;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    u32* p = data + (int64_t)f * fs;
+    u32 v[4], s = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = (i0 + e < len) ? p[i0 + e] : 0u;
+        s += v[e];
+    }
+    u32 tot;
+    u32 ex = wg_exclusive_scan(s, &tot) + part[(int64_t)f * nparts + blockIdx.x];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (i0 + e < len) p[i0 + e] = ex;
+        ex += v[e];
+    }
+}
+
+static int scan_rows(u32* data, int64_t fs, int len, int n, u32* part, u32* totals, hipStream_t st) {
+    const int nparts = (len + 1023) / 1024;
+    hipLaunchKernelGGL(scan_partials_kernel, dim3((unsigned)nparts, (unsigned)n), dim3(256), 0, st, data, fs, len, part, nparts);
+    hipLaunchKernelGGL(scan_spine_kernel, dim3((unsigned)n), dim3(256), 0, st, part, nparts, totals);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nparts, (unsigned)n), dim3(256), 0, st, data, fs, len, part, nparts);
+    return launch_status();
+}
+
+// ---- byte stuffing and the file around the entropy-coded segment ----------------------------------------------------
+
+__global__ __launch_bounds__(256) void jpeg_zero_kernel(u32* __restrict__ stream, int64_t fs_words, const u32* __restrict__ total_bits) {
+    const int f = blockIdx.y;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t need = min((int64_t)(((unsigned long long)total_bits[f] + 31) / 32 + 1), fs_words);
+    if (i >= need) return;
+    u32* p = stream + (int64_t)f * fs_words + i;
+    if (i + 4 <= fs_words) *(uint4*)p = make_uint4(0, 0, 0, 0);
+    else for (int e = 0; i + e < fs_words; ++e) p[e] = 0;
+}
+
+// byte i of frame f's unstuffed stream (MSB-first words); the last byte is completed with 1-bits (jchuff.c flush_bits)
+__device__ __forceinline__ u32 stream_byte(const u32* w, int64_t i, u32 tbits) {
+    u32 b = (w[i >> 2] >> (24 - 8 * (int)(i & 3))) & 255;
+    if ((u32)i == (tbits >> 3) && (tbits & 7)) b |= (1u << (8 - (tbits & 7))) - 1;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void jpeg_ffcount_kernel(const u32* __restrict__ stream, int64_t fs_words, const u32* __restrict__ total_bits,
+                                                           u32* __restrict__ cnt, int64_t cnt_fs, int nchunks) {
+    const int f = blockIdx.y, ci = blockIdx.x * 256 + threadIdx.x;
+    if (ci >= nchunks) return;
+    const u32 tb = total_bits[f];
+    const bool over = ((unsigned long long)tb + 31) / 32 > (unsigned long long)fs_words;
+    const int64_t nbytes = over ? 0 : ((int64_t)tb + 7) >> 3;
+    const u32* w = stream + (int64_t)f * fs_words;
+    u32 c = 0;
+    const int64_t b0 = (int64_t)ci * JCHUNK;
+    for (int e = 0; e < JCHUNK; ++e)
+        if (b0 + e < nbytes) c += stream_byte(w, b0 + e, tb) == 255;
+    cnt[(int64_t)f * cnt_fs + ci] = c;
+}
+
+__global__ __launch_bounds__(256) void jpeg_stuff_kernel(const u32* __restrict__ stream, int64_t fs_words, const u32* __restrict__ total_bits,
+                                                         const u32* __restrict__ cnt, int64_t cnt_fs, int nchunks,
+                                                         const u32* __restrict__ ff_total, u8* __restrict__ out, int64_t out_fs,
+                                                         u32* __restrict__ sizes, JpegHeader hd) {
+    const int f = blockIdx.y, ci = blockIdx.x * 256 + threadIdx.x;
+    const u32 tb = total_bits[f];
+    const bool over = ((unsigned long long)tb + 31) / 32 > (unsigned long long)fs_words;
+    const int64_t nbytes = ((int64_t)tb + 7) >> 3;
+    const int64_t fsize = (int64_t)hd.len + nbytes + ff_total[f] + 2;
+    const bool fits = !over && fsize <= out_fs;
+    u8* o = out + (int64_t)f * out_fs;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) sizes[f] = fits ? (u32)fsize : 0xffffffffu;
+        if (fits) {
+            for (int i = threadIdx.x; i < hd.len; i += 256) o[i] = hd.b[i];
+            if (threadIdx.x == 0) {
+                o[fsize - 2] = 0xff;
+                o[fsize - 1] = 0xd9;
+            }
+        }
+    }
+    if (!fits || ci >= nchunks) return;
+    const int64_t b0 = (int64_t)ci * JCHUNK;
+    if (b0 >= nbytes) return;
+    const u32* w = stream + (int64_t)f * fs_words;
+    u8* p = o + hd.len + b0 + cnt[(int64_t)f * cnt_fs + ci];
+    for (int e = 0; e < JCHUNK && b0 + e < nbytes; ++e) {
+        const u32 b = stream_byte(w, b0 + e, tb);
+        *p++ = (u8)b;
+        if (b == 255) *p++ = 0;
+    }
+}
+
+struct JpegLayout {
+    int mw, mh, bw, bh, nblk, nparts_blk, nchunks, nparts_chunk;
+    int64_t stream_words;                                  // per frame
+    size_t off_coef, off_lens, off_part, off_tot, off_stream, off_cnt, total;
+};
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static JpegLayout jpeg_layout(int n, int h, int w, size_t out_frame_stride) {
+    JpegLayout L;
+    L.mw = (w + 15) / 16;
+    L.mh = (h + 15) / 16;
+    L.bw = (w + 7) / 8;
+    L.bh = (h + 7) / 8;
+    L.nblk = L.mw * L.mh * 6;
+    L.nparts_blk = (L.nblk + 1023) / 1024;
+    L.stream_words = (int64_t)((out_frame_stride + 3) / 4 + 4) & ~(int64_t)3;
+    L.nchunks = (int)((L.stream_words * 4 + JCHUNK - 1) / JCHUNK);
+    L.nparts_chunk = (L.nchunks + 1023) / 1024;
+    size_t o = 0;
+    L.off_coef = o;   o += al256((size_t)n * L.nblk * 128);
+    L.off_lens = o;   o += al256((size_t)n * L.nblk * 4);
+    L.off_part = o;   o += al256((size_t)n * (size_t)(L.nparts_blk > L.nparts_chunk ? L.nparts_blk : L.nparts_chunk) * 4);
+    L.off_tot = o;    o += al256((size_t)n * 8);
+    L.off_stream = o; o += al256((size_t)n * L.stream_words * 4);
+    L.off_cnt = o;    o += al256((size_t)n * L.nchunks * 4);
+    L.total = o;
+    return L;
+}
+
+// exact for every |c| the DCT can produce (checked over 0 .. 65535 here): floor((a + d/2) / d), d = 8q
+static bool quant_entry(u32 qv, u32* m, u32* halfp) {
+    const u32 d = qv * 8, half = d >> 1;
+    const u32 mm = (u32)(((1ull << 32) + d - 1) / d);
+    for (u32 a = 0; a < 65536; ++a)
+        if ((a + half) / d != (u32)(((unsigned long long)(a + half) * mm) >> 32)) return false;
+    *m = mm;
+    *halfp = half;
+    return true;
+}
+
+} // namespace imgxf
+
+using namespace imgxf;
+
+IMGXF_API int imgxf_jpeg_workspace_bytes(int n, int h, int w, size_t out_frame_stride, size_t* bytes) {
+    if (!bytes) return IMGXF_ERR_NULL;
+    if (n < 0 || h < 1 || w < 1 || h > 32767 || w > 32767) return IMGXF_ERR_SHAPE;
+    *bytes = jpeg_layout(n, h, w, out_frame_stride).total;
+    return IMGXF_OK;
+}
+
+IMGXF_API int imgxf_jpeg_encode_u8(const imgxf_view* src, const imgxf_jpeg_tables* tables, const uint8_t* header,
+                                   int header_bytes, uint8_t* out, size_t out_frame_stride, uint32_t* sizes,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    IMGXF_CHECK(check_view(src));
+    if (!tables || !header || !out || !sizes) return IMGXF_ERR_NULL;
+    if (src->c != 3) return IMGXF_ERR_UNSUPPORTED;
+    if (header_bytes < 2 || header_bytes > 1024) return IMGXF_ERR_ARG;
+    if (src->n == 0) return IMGXF_OK;
+    if (empty_view(src)) return IMGXF_ERR_SHAPE;
+    if (src->n > 65535) return IMGXF_ERR_SHAPE;
+    if (out_frame_stride < (size_t)header_bytes + 2 || out_frame_stride > ((size_t)1 << 31)) return IMGXF_ERR_ARG;
+    const JpegLayout L = jpeg_layout(src->n, src->h, src->w, out_frame_stride);
+    if (!workspace || workspace_bytes < L.total || (((uintptr_t)workspace) & 15)) return IMGXF_ERR_WORKSPACE;
+    if ((int64_t)L.nblk * 2048 > 0xfffffff0ll) return IMGXF_ERR_SHAPE;        // bit offsets are 32-bit
+    JpegQuant q;
+    for (int t = 0; t < 2; ++t)
+        for (int i = 0; i < 64; ++i) {
+            const u32 qv = tables->quant[t][i];
+            if (qv < 1 || qv > 255 || !quant_entry(qv, &q.m[t][i], &q.half[t][i])) return IMGXF_ERR_ARG;
+        }
+    JpegHuff hf;
+    for (int t = 0; t < 2; ++t) {
+        for (int i = 0; i < 16; ++i) hf.dc[t][i] = (u32)tables->dc_code[t][i] | ((u32)tables->dc_len[t][i] << 16);
+        for (int i = 0; i < 256; ++i) hf.ac[t][i] = (u32)tables->ac_code[t][i] | ((u32)tables->ac_len[t][i] << 16);
+    }
+    JpegHeader hd;
+    memset(&hd, 0, sizeof(hd));
+    memcpy(hd.b, header, (size_t)header_bytes);
+    hd.len = header_bytes;
+    const View s = make_view(src);
+    hipStream_t st = (hipStream_t)stream;
+    u8* ws = (u8*)workspace;
+    int16_t* coef = (int16_t*)(ws + L.off_coef);
+    u32* lens = (u32*)(ws + L.off_lens);
+    u32* part = (u32*)(ws + L.off_part);
+    u32* tot_bits = (u32*)(ws + L.off_tot);
+    u32* tot_ff = tot_bits + s.n;
+    u32* ustream = (u32*)(ws + L.off_stream);
+    u32* cnt = (u32*)(ws + L.off_cnt);
+    const JpegGeom g = {L.mw, L.mh, L.bw, L.bh, L.nblk};
+    const int64_t coef_fs = (int64_t)L.nblk * 64;
+    hipLaunchKernelGGL(jpeg_transform_kernel, dim3((unsigned)((L.mw + JM - 1) / JM), (unsigned)L.mh, (unsigned)s.n), dim3(128), 0, st,
+                       s, coef, coef_fs, L.mw, L.bw, L.bh, q);
+    const dim3 bgrid((unsigned)((L.nblk + 255) / 256), (unsigned)s.n);
+    hipLaunchKernelGGL(jpeg_entropy_kernel<false>, bgrid, dim3(256), 0, st, (const int16_t*)coef, coef_fs, lens, (int64_t)L.nblk,
+                       (u32*)nullptr, (int64_t)0, (const u32*)nullptr, g, hf);
+    IMGXF_CHECK(scan_rows(lens, L.nblk, L.nblk, s.n, part, tot_bits, st));
+    hipLaunchKernelGGL(jpeg_zero_kernel, dim3((unsigned)((L.stream_words / 4 + 255) / 256), (unsigned)s.n), dim3(256), 0, st, ustream,
+                       L.stream_words, (const u32*)tot_bits);
+    hipLaunchKernelGGL(jpeg_entropy_kernel<true>, bgrid, dim3(256), 0, st, (const int16_t*)coef, coef_fs, lens, (int64_t)L.nblk, ustream,
+                       L.stream_words, (const u32*)tot_bits, g, hf);
+    const dim3 cgrid((unsigned)((L.nchunks + 255) / 256), (unsigned)s.n);
+    hipLaunchKernelGGL(jpeg_ffcount_kernel, cgrid, dim3(256), 0, st, (const u32*)ustream, L.stream_words, (const u32*)tot_bits, cnt,
+                       (int64_t)L.nchunks, L.nchunks);
+    IMGXF_CHECK(scan_rows(cnt, L.nchunks, L.nchunks, s.n, part, tot_ff, st));
+    hipLaunchKernelGGL(jpeg_stuff_kernel, cgrid, dim3(256), 0, st, (const u32*)ustream, L.stream_words, (const u32*)tot_bits,
+                       (const u32*)cnt, (int64_t)L.nchunks, L.nchunks, (const u32*)tot_ff, out, (int64_t)out_frame_stride, sizes, hd);
+    return launch_status();
+}

@@ -1,0 +1,123 @@
+"""Host side of the device JPEG writer (`libimgxf.so: imgxf_jpeg_encode_u8`): the save step of the reference driver,
+`transformed.save(path)` (transformation.py:161-162) → Pillow `JpegImagePlugin._save` defaults (quality 75, 4:2:0,
+Annex-K Huffman tables, no optimisation) → libjpeg-turbo.  This module holds what the host contributes — the quality →
+quantisation-table rule (jcparam.c jpeg_set_quality), the canonical Huffman codes of the Annex-K tables (jchuff.c
+jpeg_make_c_derived_tbl), the marker segments before the scan (jcmarker.c) — and `encode`, which runs a batch of frames
+through the kernels and returns one `bytes` per frame.  Nothing here computes pixels; there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+from functools import lru_cache
+from typing import List
+
+import torch
+
+from . import _ffi as F
+
+ZIGZAG = (0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
+          28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61,
+          54, 47, 55, 62, 63)
+# ITU-T T.81 Annex K.1 / K.2 (natural order) and K.3 – K.6
+LUMINANCE_Q = (16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29,
+               51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121,
+               120, 101, 72, 92, 95, 98, 112, 100, 103, 99)
+CHROMINANCE_Q = (17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99,
+                 99, 99, 99, 99, 99) + (99,) * 32
+DC_BITS = ((0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0), (0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0))
+DC_VALS = (tuple(range(12)), tuple(range(12)))
+AC_BITS = ((0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 125), (0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 119))
+AC_VALS = (bytes.fromhex(
+    "01020300041105122131410613516107227114328191a1082342b1c11552d1f02433627282090a161718191a25262728292a3435363738393a43"
+    "4445464748494a535455565758595a636465666768696a737475767778797a838485868788898a92939495969798999aa2a3a4a5a6a7a8a9aab2"
+    "b3b4b5b6b7b8b9bac2c3c4c5c6c7c8c9cad2d3d4d5d6d7d8d9dae1e2e3e4e5e6e7e8e9eaf1f2f3f4f5f6f7f8f9fa"), bytes.fromhex(
+    "0001020311040521310612415107617113223281081442 91a1b1c109233352f0156272d10a162434e125f11718191a262728292a35363738393a43"
+    "4445464748494a535455565758595a636465666768696a737475767778797a82838485868788898a92939495969798999aa2a3a4a5a6a7a8a9aab2"
+    "b3b4b5b6b7b8b9bac2c3c4c5c6c7c8c9cad2d3d4d5d6d7d8d9dae2e3e4e5e6e7e8e9eaf2f3f4f5f6f7f8f9fa".replace(" ", "")))
+
+
+def quant_tables(quality: int = 75):
+    """jpeg_set_quality(quality, force_baseline=TRUE): two 64-entry tables, natural order."""
+    q = min(max(int(quality), 1), 100)
+    scale = 5000 // q if q < 50 else 200 - 2 * q
+    return tuple(tuple(min(max((v * scale + 50) // 100, 1), 255) for v in base) for base in (LUMINANCE_Q, CHROMINANCE_Q))
+
+
+def _codes(bits, vals):
+    out, code, k = {}, 0, 0
+    for length in range(1, 17):
+        for _ in range(bits[length - 1]):
+            out[vals[k]] = (code, length)
+            code += 1
+            k += 1
+        code <<= 1
+    return out
+
+
+@lru_cache(maxsize=16)
+def tables(quality: int = 75) -> F.JpegTables:
+    t = F.JpegTables()
+    for i, qt in enumerate(quant_tables(quality)):
+        for j, v in enumerate(qt):
+            t.quant[i][j] = v
+        for sym, (code, length) in _codes(DC_BITS[i], DC_VALS[i]).items():
+            t.dc_code[i][sym], t.dc_len[i][sym] = code, length
+        for sym, (code, length) in _codes(AC_BITS[i], AC_VALS[i]).items():
+            t.ac_code[i][sym], t.ac_len[i][sym] = code, length
+    return t
+
+
+def header(width: int, height: int, quality: int = 75) -> bytes:
+    """SOI, APP0 (JFIF 1.01, no density), DQT ×2, SOF0 (Y 2×2, Cb / Cr 1×1), DHT ×4, SOS — jcmarker.c's order."""
+    if not (0 < width < 65536 and 0 < height < 65536):
+        raise ValueError("JPEG dimensions must be 1..65535")
+    out = bytearray(b"\xff\xd8\xff\xe0\x00\x10JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+    for i, qt in enumerate(quant_tables(quality)):
+        out += b"\xff\xdb\x00\x43" + bytes([i]) + bytes(qt[z] for z in ZIGZAG)
+    out += b"\xff\xc0\x00\x11\x08" + height.to_bytes(2, "big") + width.to_bytes(2, "big") + b"\x03\x01\x22\x00\x02\x11\x01\x03\x11\x01"
+    for i in range(2):
+        for cls, bits, vals in ((0x00, DC_BITS[i], DC_VALS[i]), (0x10, AC_BITS[i], AC_VALS[i])):
+            out += b"\xff\xc4" + (19 + len(vals)).to_bytes(2, "big") + bytes([cls | i]) + bytes(bits) + bytes(vals)
+    out += b"\xff\xda\x00\x0c\x03\x01\x00\x02\x11\x03\x11\x00\x3f\x00"
+    return bytes(out)
+
+
+def encode_device(frames: torch.Tensor, quality: int = 75, capacity: int | None = None):
+    """[N, H, W, 3] uint8 device tensor → (files [N, capacity] uint8, sizes [N] int64 on the device); frame f's file is
+    files[f, :sizes[f]].  Raises ImgxfError if a file does not fit in `capacity` bytes."""
+    if frames.dim() != 4 or frames.shape[-1] != 3 or frames.dtype != torch.uint8:
+        raise ValueError("jpeg.encode expects a [N, H, W, 3] uint8 tensor")
+    if not frames.is_cuda:
+        raise F.ImgxfError(F.ERR_NO_DEVICE, "frames must live on the GPU (no CPU fallback)", "jpeg.encode")
+    n, h, w, _ = frames.shape
+    hdr = header(w, h, quality)
+    cap = int(capacity) if capacity is not None else 2 * h * w + 4096
+    cap = (cap + 15) & ~15
+    files = torch.empty((n, cap), dtype=torch.uint8, device=frames.device)
+    sizes = torch.zeros((n,), dtype=torch.int32, device=frames.device)
+    if n == 0:
+        return files, sizes.to(torch.int64)
+    frames = frames if frames.stride(-1) == 1 and frames.stride(-2) == 3 else frames.contiguous()
+    nbytes = ctypes.c_size_t()
+    F.call("imgxf_jpeg_workspace_bytes", n, h, w, cap, ctypes.byref(nbytes))
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=frames.device)
+    view = F.view_of(frames)
+    F.call("imgxf_jpeg_encode_u8", F.vp(view), ctypes.addressof(tables(quality)), hdr, len(hdr), files.data_ptr(), cap,
+           sizes.data_ptr(), ws.data_ptr(), nbytes.value, torch.cuda.current_stream(frames.device).cuda_stream)
+    return files, sizes.to(torch.int64) & 0xFFFFFFFF
+
+
+def encode(frames: torch.Tensor, quality: int = 75, capacity: int | None = None) -> List[bytes]:
+    """One JPEG file (`bytes`) per frame, equal to Pillow's `Image.fromarray(frame).save(fp, "JPEG", quality=quality)`."""
+    n, h, w = frames.shape[0], frames.shape[1], frames.shape[2]
+    files, sizes = encode_device(frames, quality, capacity)
+    lens = sizes.cpu().tolist()
+    if any(v == 0xFFFFFFFF for v in lens):
+        if capacity is not None:
+            raise F.ImgxfError(F.ERR_WORKSPACE, f"a JPEG stream does not fit in capacity={capacity} bytes", "jpeg.encode")
+        files, sizes = encode_device(frames, quality, 12 * h * w + 4096)      # beyond any baseline stream of this size
+        lens = sizes.cpu().tolist()
+        if any(v == 0xFFFFFFFF for v in lens):
+            raise F.ImgxfError(F.ERR_WORKSPACE, "a JPEG stream exceeds 12 bytes per pixel", "jpeg.encode")
+    top = max(lens) if lens else 0
+    host = files[:, :top].cpu().numpy()
+    return [host[i, :lens[i]].tobytes() for i in range(n)]

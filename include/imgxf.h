@@ -304,6 +304,26 @@ int imgxf_to_tensor_f32(const imgxf_view* src, float* dst, const float* mean, co
 int imgxf_perspective_bilinear_u8(const imgxf_view* src, const imgxf_view* dst,
                                   const float* coeffs, int per_frame, void* stream);
 
+/* ---- the driver's save step  transformation.py:161-162 (`transformed.save(path)`: Pillow ->
+ * libjpeg-turbo baseline JPEG, 4:2:0, islow DCT, no restart markers) ------------------------*/
+typedef struct imgxf_jpeg_tables {
+    uint16_t quant[2][64];      /* luminance / chrominance divisors 1..255, natural (row-major) order */
+    uint16_t dc_code[2][16];    /* Huffman code of DC magnitude category 0..11 (table 0: Y, 1: Cb/Cr) */
+    uint8_t  dc_len[2][16];
+    uint16_t ac_code[2][256];   /* Huffman code of the AC symbol (run << 4) | size */
+    uint8_t  ac_len[2][256];
+} imgxf_jpeg_tables;
+/* One complete JPEG file per frame of a c == 3 view: out + f*out_frame_stride holds `header`
+ * (host bytes, SOI .. SOS as the caller built them for these tables and this size, <= 1024),
+ * the entropy-coded segment, EOI; sizes[f] (device) = the file's length, or 0xFFFFFFFF when it
+ * does not fit in out_frame_stride bytes (nothing usable is written for that frame).
+ * Bit-identical to libjpeg(-turbo)'s output for the same tables.  workspace: device, 16-byte
+ * aligned, >= imgxf_jpeg_workspace_bytes(n, h, w, out_frame_stride). */
+int imgxf_jpeg_workspace_bytes(int n, int h, int w, size_t out_frame_stride, size_t* bytes);
+int imgxf_jpeg_encode_u8(const imgxf_view* src, const imgxf_jpeg_tables* tables, const uint8_t* header,
+                         int header_bytes, uint8_t* out, size_t out_frame_stride, uint32_t* sizes,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- mask stage of apply_background_change  transformation.py:340-341 -----------------*/
 /* 256-bin histogram per frame of a c==1 view into hist[n][256] (uint32, device, zeroed by the call). */
 int imgxf_histogram_u8(const imgxf_view* src, uint32_t* hist, void* stream);

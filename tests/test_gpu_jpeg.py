@@ -1,0 +1,127 @@
+"""Device JPEG writer (`imagetransformations_amd.jpeg`, `imgxf_jpeg_encode_u8`) against Pillow's own encoder — the library
+behind the reference driver's `transformed.save(path)` (transformation.py:161-162) — the CPU restatement and the
+committed fixtures: whole files, byte for byte."""
+import hashlib, importlib.util, io, json, os
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+_spec = importlib.util.spec_from_file_location("make_jpeg_golden", os.path.join(HERE, "golden", "make_jpeg_golden.py"))
+G = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(G)
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "jpeg_q75.json")))
+
+
+def pil_bytes(a, **kw):
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def gpu_bytes(a, quality=75, **kw):
+    from imagetransformations_amd import jpeg
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return jpeg.encode(t if t.dim() == 4 else t[None], quality, **kw)
+
+
+def first_diff(a, b):
+    n = min(len(a), len(b))
+    return next((i for i in range(n) if a[i] != b[i]), n)
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: f"{c['h']}x{c['w']}-{c['kind']}-q{c['quality']}")
+def test_fixture(case):
+    img = G.image(case["h"], case["w"], case["kind"], case["seed"])
+    out = gpu_bytes(img, 75 if case["quality"] is None else case["quality"])[0]
+    assert len(out) == case["bytes"]
+    assert hashlib.sha256(out).hexdigest() == case["sha256"]
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (7, 9), (8, 8), (15, 17), (16, 16), (16, 256), (16, 257), (17, 255), (31, 300),
+                                   (33, 511), (64, 48), (100, 75), (375, 500), (32, 32), (240, 1000), (1080, 1920)])
+def test_equals_pillow_and_oracle(shape):
+    from oracle import jpeg_oracle as J
+    rng = np.random.default_rng(shape[0] * 7919 + shape[1])
+    for kind in range(3):
+        if kind == 0:
+            a = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+        elif kind == 1:
+            yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+            a = np.stack([(xx * 3 + yy) % 256, (xx + yy * 2) % 256, (xx * yy) % 256], -1).astype(np.uint8)
+        else:
+            a = np.full(shape + (3,), rng.integers(0, 256), np.uint8)
+            a[shape[0] // 2:, :, 1] = 255
+        want, got = pil_bytes(a), gpu_bytes(a)[0]
+        assert len(got) == len(want) and got == want, f"kind {kind}: first difference at byte {first_diff(got, want)} of {len(want)}"
+        if shape[0] * shape[1] <= 200000:
+            assert J.encode(a) == got
+
+
+@pytest.mark.parametrize("quality", [1, 10, 50, 90, 95, 100])
+def test_qualities(quality):
+    rng = np.random.default_rng(quality)
+    a = rng.integers(0, 256, (75, 130, 3), dtype=np.uint8)
+    assert gpu_bytes(a, quality)[0] == pil_bytes(a, quality=quality)
+    b = (rng.integers(0, 256, (75, 130, 3)) // 64 * 60 + 10).astype(np.uint8)
+    assert gpu_bytes(b, quality)[0] == pil_bytes(b, quality=quality)
+
+
+def test_batch_frames_are_independent_files():
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (9, 50, 70, 3), dtype=np.uint8)
+    a[3] = 0
+    a[4] = 255
+    a[5, :, :, :] = np.arange(70, dtype=np.uint8)[None, :, None] * 3
+    out = gpu_bytes(a)
+    assert len(out) == 9
+    for i in range(9):
+        assert out[i] == pil_bytes(a[i]), i
+
+
+def test_strided_and_unaligned_views():
+    from imagetransformations_amd import jpeg
+    rng = np.random.default_rng(6)
+    big = torch.from_numpy(rng.integers(0, 256, (3, 300, 600, 3), dtype=np.uint8)).cuda()
+    view = big[:, 5:277, 3:515, :]                      # row stride 1800, base offset 9 bytes: not 16-byte aligned
+    out = jpeg.encode(view)
+    for i in range(3):
+        assert out[i] == pil_bytes(view[i].cpu().numpy())
+    aligned = torch.from_numpy(rng.integers(0, 256, (2, 64, 512, 3), dtype=np.uint8)).cuda()
+    out = jpeg.encode(aligned)
+    for i in range(2):
+        assert out[i] == pil_bytes(aligned[i].cpu().numpy())
+
+
+def test_4k_frame():
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:2160, 0:3840]
+    a = np.stack([(xx // 7 + yy // 3) % 256, (xx // 2 + yy // 5) % 256, (xx // 11 * 3 + yy // 13) % 256], -1).astype(np.uint8)
+    a[500:900, 700:1900] = rng.integers(0, 256, (400, 1200, 3), dtype=np.uint8)
+    got = gpu_bytes(a)[0]
+    want = pil_bytes(a)
+    assert got == want, first_diff(got, want)
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(got))), np.asarray(Image.open(io.BytesIO(want))))
+
+
+def test_capacity_is_enforced_loudly_and_default_grows():
+    from imagetransformations_amd import jpeg, _ffi
+    rng = np.random.default_rng(8)
+    a = torch.from_numpy(rng.integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)).cuda()
+    with pytest.raises(_ffi.ImgxfError):
+        jpeg.encode(a, 100, capacity=2048)
+    files, sizes = jpeg.encode_device(a, 100, capacity=2048)
+    assert sizes.cpu().tolist() == [0xFFFFFFFF] * 2
+    out = jpeg.encode(a, 100)                                  # q=100 noise: > 2 bytes per pixel, the default retries larger
+    assert out[0] == pil_bytes(a[0].cpu().numpy(), quality=100)
+
+
+def test_argument_errors():
+    from imagetransformations_amd import jpeg
+    with pytest.raises(ValueError):
+        jpeg.encode(torch.zeros((1, 8, 8, 4), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        jpeg.encode(torch.zeros((1, 8, 8, 3), dtype=torch.float32, device="cuda"))
+    assert jpeg.encode(torch.zeros((0, 8, 8, 3), dtype=torch.uint8, device="cuda")) == []
