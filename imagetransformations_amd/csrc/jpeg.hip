@@ -5,8 +5,9 @@
 //   jpeg_transform_kernel   RGB → YCbCr (16-bit fixed point) → 2×2 chroma averaging → 8×8 forward DCT → quantise;
 //                           16 MCUs (16×256 px) per workgroup staged through LDS, one thread per 8×8 block, zigzag
 //                           int16 coefficients in MCU order (6 blocks per MCU) to the workspace
-//   jpeg_entropy_kernel<0>  bits per block (DC difference + run/size symbols)          → exclusive scan = bit offsets
-//   jpeg_entropy_kernel<1>  the same walk, emitting the codes at the block's bit offset (atomic OR at shared words)
+//                           plus, per block, its DC value and the bits its AC symbols will take
+//   jpeg_lens_kernel        bits per block (DC difference code + AC bits)               → exclusive scan = bit offsets
+//   jpeg_emit_kernel        256 blocks per workgroup through LDS, codes written at the block's bit offset
 //   jpeg_ffcount / jpeg_stuff_kernel   0xFF → 0xFF 0x00 byte stuffing (count per 32-byte chunk, scan, scatter),
 //                           header, padding of the last byte with 1-bits, EOI, file size per frame
 //
@@ -22,6 +23,7 @@ constexpr int JCHUNK = 32;                   // bytes per stuffing thread
 struct JpegQuant {                           // per coefficient (natural order): |c| → ((|c| + half) · m) >> 32
     u32 m[2][64];                            // ceil(2^32 / 8q)
     u32 half[2][64];                         // 4q
+    u8 aclen[2][256];                        // Huffman code length of the AC symbol (run << 4) | size
 };
 struct JpegHuff {                            // code | len << 16
     u32 dc[2][16];
@@ -79,13 +81,16 @@ constexpr int zz(int i) {
 
 // One workgroup: rows y0 .. y0+15, columns x0 .. x0+255 of frame f.  128 threads: both waves stage and convert, then
 // wave 0 transforms the 64 luminance blocks and the lower half of wave 1 the 32 chrominance blocks.
-__global__ __launch_bounds__(128) void jpeg_transform_kernel(View s, int16_t* __restrict__ coef, int64_t coef_fs, int mw,
+__global__ __launch_bounds__(128) void jpeg_transform_kernel(View s, int16_t* __restrict__ coef, int64_t coef_fs,
+                                                             int16_t* __restrict__ dcs, uint16_t* __restrict__ acbits, int mw,
                                                              int bw, int bh, JpegQuant q) {
+    __shared__ __attribute__((aligned(4))) u8 slen[2][256];
     __shared__ __attribute__((aligned(16))) u8 rgb[16][768];
     __shared__ __attribute__((aligned(16))) u8 yp[16][256 + 8];
     __shared__ __attribute__((aligned(16))) u8 cp[2][8][128 + 8];
     const int tid = threadIdx.x, f = blockIdx.z, my = blockIdx.y, mx0 = blockIdx.x * JM;
     const int y0 = my * 16, x0 = mx0 * 16;
+    ((u32*)slen)[tid] = ((const u32*)q.aclen)[tid];
     const u8* base = s.p + (int64_t)f * s.fs;
     const bool fast = (x0 + 256 <= s.w) && (((uintptr_t)base | (uintptr_t)s.rs) & 15) == 0;
     for (int i = tid; i < 16 * 48; i += 128) {
@@ -182,7 +187,24 @@ __global__ __launch_bounds__(128) void jpeg_transform_kernel(View s, int16_t* __
         const u32 qq = __umulhi(a + q.half[chroma][i], q.m[chroma][i]);
         d[i] = ((int)qq ^ sg) - sg;
     }
-    uint4* out = (uint4*)(coef + (int64_t)f * coef_fs + ((int64_t)((int64_t)my * mw + mx0 + ml) * 6 + k) * 64);
+    const int64_t blk = ((int64_t)my * mw + mx0 + ml) * 6 + k;
+    {   // bits of the AC part of this block (jchuff.c encode_one_block), so that only the DC term needs the neighbours
+        const u8* lt = slen[chroma];
+        u32 bits = 0, run = 0;
+#pragma unroll
+        for (int i = 1; i < 64; ++i) {
+            const int c = d[zz(i)], sg = c >> 31;
+            const u32 a = (u32)((c ^ sg) - sg);
+            const u32 cat = 32 - (u32)__clz((int)a);          // 0 for a == 0
+            const u32 add = (run >> 4) * lt[0xF0] + lt[((run & 15) << 4) | (cat & 15)] + cat;
+            bits += a ? add : 0u;
+            run = a ? 0u : run + 1;
+        }
+        if (run) bits += lt[0];
+        acbits[(int64_t)f * (coef_fs / 64) + blk] = (uint16_t)bits;
+        dcs[(int64_t)f * (coef_fs / 64) + blk] = (int16_t)d[0];
+    }
+    uint4* out = (uint4*)(coef + (int64_t)f * coef_fs + blk * 64);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         uint4 v;
@@ -213,84 +235,108 @@ __device__ __forceinline__ int dc_source(const JpegGeom& g, int mx, int my, int 
     return k - 1;                                              // right edge: the block to its left
 }
 
-template <bool EMIT>
-__global__ __launch_bounds__(256) void jpeg_entropy_kernel(const int16_t* __restrict__ coef, int64_t coef_fs, u32* __restrict__ lens,
-                                                           int64_t lens_fs, u32* __restrict__ stream, int64_t stream_fs_words,
-                                                           const u32* __restrict__ total_bits, JpegGeom g, JpegHuff hf) {
-    __shared__ u32 sdc[2][16];
-    __shared__ u32 sac[2][256];
-    for (int i = threadIdx.x; i < 32; i += 256) sdc[i >> 4][i & 15] = hf.dc[i >> 4][i & 15];
-    for (int i = threadIdx.x; i < 512; i += 256) sac[i >> 8][i & 255] = hf.ac[i >> 8][i & 255];
-    __syncthreads();
+// DC value carried by block k of MCU (mx, my), and the one the DC difference is taken against (the block of the same
+// component before it in scan order; 0 at the start of the frame).
+__device__ __forceinline__ int block_dc(const int16_t* __restrict__ dcs, const JpegGeom& g, int mcu, int mx, int my, int k, bool& dummy) {
+    return dcs[(int64_t)mcu * 6 + dc_source(g, mx, my, k, dummy)];
+}
+__device__ __forceinline__ int block_pred(const int16_t* __restrict__ dcs, const JpegGeom& g, int mcu, int mx, int my, int k) {
+    bool pd;
+    if (k >= 4) return mcu > 0 ? dcs[(int64_t)(mcu - 1) * 6 + k] : 0;
+    if (k > 0) return block_dc(dcs, g, mcu, mx, my, k - 1, pd);
+    if (mcu == 0) return 0;
+    const int pm = mcu - 1, pmy = pm / g.mw, pmx = pm - pmy * g.mw;
+    return block_dc(dcs, g, pm, pmx, pmy, 3, pd);
+}
+
+// bits of every block: DC category code + magnitude bits + the AC bits the transform kernel counted (EOB for a dummy)
+__global__ __launch_bounds__(256) void jpeg_lens_kernel(const int16_t* __restrict__ dcs, const uint16_t* __restrict__ acbits,
+                                                        u32* __restrict__ lens, JpegGeom g, JpegHuff hf) {
     const int j = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
     if (j >= g.nblk) return;
     const int mcu = j / 6, k = j - mcu * 6, my = mcu / g.mw, mx = mcu - my * g.mw;
-    const int16_t* cf = coef + (int64_t)f * coef_fs;
-    bool dummy, pd;
-    const int src = dc_source(g, mx, my, k, dummy);
-    const int dcv = cf[((int64_t)mcu * 6 + src) * 64];
-    int pred = 0;
-    if (k >= 4) {
-        if (mcu > 0) pred = cf[((int64_t)(mcu - 1) * 6 + k) * 64];
-    } else if (k > 0) {
-        pred = cf[((int64_t)mcu * 6 + dc_source(g, mx, my, k - 1, pd)) * 64];
-    } else if (mcu > 0) {
-        const int pm = mcu - 1, pmy = pm / g.mw, pmx = pm - pmy * g.mw;
-        pred = cf[((int64_t)pm * 6 + dc_source(g, pmx, pmy, 3, pd)) * 64];
-    }
-    const int t = k >= 4 ? 1 : 0;
-    u32 bits = 0;
-    unsigned long long acc = 0;
-    u32 nb = 0;
-    u32* wp = nullptr;
-    bool first = true;
-    if (EMIT) {
-        if (((unsigned long long)total_bits[f] + 31) / 32 > (unsigned long long)stream_fs_words) return;   // reported by jpeg_stuff_kernel
-        const u32 off = lens[(int64_t)f * lens_fs + j];
-        nb = off & 31;
-        wp = stream + (int64_t)f * stream_fs_words + (off >> 5);
-    }
-    auto put = [&](u32 code, u32 len) {
-        if (EMIT) {
-            acc |= (unsigned long long)code << (64 - nb - len);
-            nb += len;
-            if (nb >= 32) {
-                if (first) atomicOr(wp, (u32)(acc >> 32));
-                else *wp = (u32)(acc >> 32);
-                first = false;
-                ++wp;
-                acc <<= 32;
-                nb -= 32;
+    const int16_t* dd = dcs + (int64_t)f * g.nblk;
+    bool dummy;
+    const int diff = block_dc(dd, g, mcu, mx, my, k, dummy) - block_pred(dd, g, mcu, mx, my, k);
+    const int sg = diff >> 31, t = k >= 4 ? 1 : 0;
+    const u32 cat = 32 - (u32)__clz((diff ^ sg) - sg);
+    lens[(int64_t)f * g.nblk + j] = (hf.dc[t][cat] >> 16) + cat + (dummy ? hf.ac[t][0] >> 16 : (u32)acbits[(int64_t)f * g.nblk + j]);
+}
+
+// 256 blocks per workgroup: their 32 KB of coefficients are staged through LDS with coalesced loads (row stride 33
+// dwords, so that the per-thread walks below hit different banks), then every thread emits its block's codes at the
+// block's bit offset: the first word it touches is shared with the previous block (atomic OR), the words after it are
+// its own (plain stores), the last partial word is shared with the next block (atomic OR).
+__global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* __restrict__ coef, int64_t coef_fs, const int16_t* __restrict__ dcs,
+                                                        const u32* __restrict__ offs, u32* __restrict__ stream, int64_t stream_fs_words,
+                                                        const u32* __restrict__ total_bits, JpegGeom g, JpegHuff hf) {
+    __shared__ u32 sdc[2][16];
+    __shared__ u32 sac[2][256];
+    __shared__ u32 sco[256 * 33];
+    const int f = blockIdx.y, j0 = blockIdx.x * 256, j = j0 + threadIdx.x;
+    if (((unsigned long long)total_bits[f] + 31) / 32 > (unsigned long long)stream_fs_words) return;   // reported by jpeg_stuff_kernel
+    for (int i = threadIdx.x; i < 32; i += 256) sdc[i >> 4][i & 15] = hf.dc[i >> 4][i & 15];
+    for (int i = threadIdx.x; i < 512; i += 256) sac[i >> 8][i & 255] = hf.ac[i >> 8][i & 255];
+    {
+        const uint4* src = (const uint4*)(coef + (int64_t)f * coef_fs + (int64_t)j0 * 64);
+        const int nv = min(256, g.nblk - j0) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            if (idx < nv) {
+                const uint4 v = src[idx];
+                u32* dst = &sco[(idx >> 3) * 33 + (idx & 7) * 4];
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
             }
-        } else {
-            bits += len;
+        }
+    }
+    __syncthreads();
+    if (j >= g.nblk) return;
+    const int mcu = j / 6, k = j - mcu * 6, my = mcu / g.mw, mx = mcu - my * g.mw;
+    const int16_t* dd = dcs + (int64_t)f * g.nblk;
+    bool dummy;
+    const int diff = block_dc(dd, g, mcu, mx, my, k, dummy) - block_pred(dd, g, mcu, mx, my, k);
+    const int t = k >= 4 ? 1 : 0;
+    const u32 off = offs[(int64_t)f * g.nblk + j];
+    unsigned long long acc = 0;
+    u32 nb = off & 31;
+    u32* wp = stream + (int64_t)f * stream_fs_words + (off >> 5);
+    bool first = true;
+    auto put = [&](u32 code, u32 len) {
+        acc |= (unsigned long long)code << (64 - nb - len);
+        nb += len;
+        if (nb >= 32) {
+            if (first) atomicOr(wp, (u32)(acc >> 32));
+            else *wp = (u32)(acc >> 32);
+            first = false;
+            ++wp;
+            acc <<= 32;
+            nb -= 32;
         }
     };
     {
-        const int diff = dcv - pred, sg = diff >> 31;
-        const u32 ad = (u32)((diff ^ sg) - sg);
-        const u32 cat = ad ? 32 - __builtin_clz(ad) : 0;
+        const int sg = diff >> 31;
+        const u32 cat = 32 - (u32)__clz((diff ^ sg) - sg);
         const u32 e = sdc[t][cat];
         put(((e & 0xffff) << cat) | ((u32)(diff + sg) & ((1u << cat) - 1)), (e >> 16) + cat);
     }
     if (!dummy) {
-        const uint4* blk = (const uint4*)(cf + ((int64_t)mcu * 6 + k) * 64);
+        const u32* blk = &sco[threadIdx.x * 33];
         const u32 zrl = sac[t][0xF0];
         u32 run = 0;
-        for (int gidx = 0; gidx < 8; ++gidx) {
-            const uint4 v = blk[gidx];
-            const u32 w[4] = {v.x, v.y, v.z, v.w};
+        for (int w = 0; w < 32; ++w) {
+            const u32 pair = blk[w];
 #pragma unroll
-            for (int e8 = 0; e8 < 8; ++e8) {
-                if (gidx == 0 && e8 == 0) continue;
-                const int c = (int)(int16_t)(w[e8 >> 1] >> (16 * (e8 & 1)));
+            for (int h = 0; h < 2; ++h) {
+                if (w == 0 && h == 0) continue;
+                const int c = (int)(int16_t)(pair >> (16 * h));
                 if (c == 0) {
                     ++run;
                     continue;
                 }
                 for (u32 z = run >> 4; z > 0; --z) put(zrl & 0xffff, zrl >> 16);
                 const int sg = c >> 31;
-                const u32 cat = 32 - __builtin_clz((c ^ sg) - sg);
+                const u32 cat = 32 - (u32)__clz((c ^ sg) - sg);
                 const u32 e = sac[t][((run & 15) << 4) | cat];
                 put(((e & 0xffff) << cat) | ((u32)(c + sg) & ((1u << cat) - 1)), (e >> 16) + cat);
                 run = 0;
@@ -304,11 +350,7 @@ __global__ __launch_bounds__(256) void jpeg_entropy_kernel(const int16_t* __rest
         const u32 e = sac[t][0];
         put(e & 0xffff, e >> 16);
     }
-    if (EMIT) {
-        if (nb) atomicOr(wp, (u32)(acc >> 32));
-    } else {
-        lens[(int64_t)f * lens_fs + j] = bits;
-    }
+    if (nb) atomicOr(wp, (u32)(acc >> 32));
 }
 
 // ---- exclusive scan of u32 rows (in place), 1024 elements per workgroup ---------------------------------------------
@@ -462,7 +504,7 @@ __global__ __launch_bounds__(256) void jpeg_stuff_kernel(const u32* __restrict__
 struct JpegLayout {
     int mw, mh, bw, bh, nblk, nparts_blk, nchunks, nparts_chunk;
     int64_t stream_words;                                  // per frame
-    size_t off_coef, off_lens, off_part, off_tot, off_stream, off_cnt, total;
+    size_t off_coef, off_dcs, off_acb, off_lens, off_part, off_tot, off_stream, off_cnt, total;
 };
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -480,6 +522,8 @@ static JpegLayout jpeg_layout(int n, int h, int w, size_t out_frame_stride) {
     L.nparts_chunk = (L.nchunks + 1023) / 1024;
     size_t o = 0;
     L.off_coef = o;   o += al256((size_t)n * L.nblk * 128);
+    L.off_dcs = o;    o += al256((size_t)n * L.nblk * 2);
+    L.off_acb = o;    o += al256((size_t)n * L.nblk * 2);
     L.off_lens = o;   o += al256((size_t)n * L.nblk * 4);
     L.off_part = o;   o += al256((size_t)n * (size_t)(L.nparts_blk > L.nparts_chunk ? L.nparts_blk : L.nparts_chunk) * 4);
     L.off_tot = o;    o += al256((size_t)n * 8);
@@ -490,13 +534,26 @@ static JpegLayout jpeg_layout(int n, int h, int w, size_t out_frame_stride) {
 }
 
 // exact for every |c| the DCT can produce (checked over 0 .. 65535 here): floor((a + d/2) / d), d = 8q
+struct QuantMagic {
+    u32 m[256];
+    bool ok[256];
+    QuantMagic() {
+        for (u32 qv = 1; qv < 256; ++qv) {
+            const u32 d = qv * 8, half = d >> 1;
+            m[qv] = (u32)(((1ull << 32) + d - 1) / d);
+            ok[qv] = true;
+            for (u32 a = 0; a < 65536 && ok[qv]; ++a)
+                ok[qv] = (a + half) / d == (u32)(((unsigned long long)(a + half) * m[qv]) >> 32);
+        }
+        m[0] = 0;
+        ok[0] = false;
+    }
+};
 static bool quant_entry(u32 qv, u32* m, u32* halfp) {
-    const u32 d = qv * 8, half = d >> 1;
-    const u32 mm = (u32)(((1ull << 32) + d - 1) / d);
-    for (u32 a = 0; a < 65536; ++a)
-        if ((a + half) / d != (u32)(((unsigned long long)(a + half) * mm) >> 32)) return false;
-    *m = mm;
-    *halfp = half;
+    static const QuantMagic magic;                          // built (and checked) once per process
+    if (qv > 255 || !magic.ok[qv]) return false;
+    *m = magic.m[qv];
+    *halfp = qv * 4;
     return true;
 }
 
@@ -534,7 +591,10 @@ IMGXF_API int imgxf_jpeg_encode_u8(const imgxf_view* src, const imgxf_jpeg_table
     JpegHuff hf;
     for (int t = 0; t < 2; ++t) {
         for (int i = 0; i < 16; ++i) hf.dc[t][i] = (u32)tables->dc_code[t][i] | ((u32)tables->dc_len[t][i] << 16);
-        for (int i = 0; i < 256; ++i) hf.ac[t][i] = (u32)tables->ac_code[t][i] | ((u32)tables->ac_len[t][i] << 16);
+        for (int i = 0; i < 256; ++i) {
+            hf.ac[t][i] = (u32)tables->ac_code[t][i] | ((u32)tables->ac_len[t][i] << 16);
+            q.aclen[t][i] = tables->ac_len[t][i];
+        }
     }
     JpegHeader hd;
     memset(&hd, 0, sizeof(hd));
@@ -544,6 +604,8 @@ IMGXF_API int imgxf_jpeg_encode_u8(const imgxf_view* src, const imgxf_jpeg_table
     hipStream_t st = (hipStream_t)stream;
     u8* ws = (u8*)workspace;
     int16_t* coef = (int16_t*)(ws + L.off_coef);
+    int16_t* dcs = (int16_t*)(ws + L.off_dcs);
+    uint16_t* acb = (uint16_t*)(ws + L.off_acb);
     u32* lens = (u32*)(ws + L.off_lens);
     u32* part = (u32*)(ws + L.off_part);
     u32* tot_bits = (u32*)(ws + L.off_tot);
@@ -553,15 +615,14 @@ IMGXF_API int imgxf_jpeg_encode_u8(const imgxf_view* src, const imgxf_jpeg_table
     const JpegGeom g = {L.mw, L.mh, L.bw, L.bh, L.nblk};
     const int64_t coef_fs = (int64_t)L.nblk * 64;
     hipLaunchKernelGGL(jpeg_transform_kernel, dim3((unsigned)((L.mw + JM - 1) / JM), (unsigned)L.mh, (unsigned)s.n), dim3(128), 0, st,
-                       s, coef, coef_fs, L.mw, L.bw, L.bh, q);
+                       s, coef, coef_fs, dcs, acb, L.mw, L.bw, L.bh, q);
     const dim3 bgrid((unsigned)((L.nblk + 255) / 256), (unsigned)s.n);
-    hipLaunchKernelGGL(jpeg_entropy_kernel<false>, bgrid, dim3(256), 0, st, (const int16_t*)coef, coef_fs, lens, (int64_t)L.nblk,
-                       (u32*)nullptr, (int64_t)0, (const u32*)nullptr, g, hf);
+    hipLaunchKernelGGL(jpeg_lens_kernel, bgrid, dim3(256), 0, st, (const int16_t*)dcs, (const uint16_t*)acb, lens, g, hf);
     IMGXF_CHECK(scan_rows(lens, L.nblk, L.nblk, s.n, part, tot_bits, st));
     hipLaunchKernelGGL(jpeg_zero_kernel, dim3((unsigned)((L.stream_words / 4 + 255) / 256), (unsigned)s.n), dim3(256), 0, st, ustream,
                        L.stream_words, (const u32*)tot_bits);
-    hipLaunchKernelGGL(jpeg_entropy_kernel<true>, bgrid, dim3(256), 0, st, (const int16_t*)coef, coef_fs, lens, (int64_t)L.nblk, ustream,
-                       L.stream_words, (const u32*)tot_bits, g, hf);
+    hipLaunchKernelGGL(jpeg_emit_kernel, bgrid, dim3(256), 0, st, (const int16_t*)coef, coef_fs, (const int16_t*)dcs, (const u32*)lens,
+                       ustream, L.stream_words, (const u32*)tot_bits, g, hf);
     const dim3 cgrid((unsigned)((L.nchunks + 255) / 256), (unsigned)s.n);
     hipLaunchKernelGGL(jpeg_ffcount_kernel, cgrid, dim3(256), 0, st, (const u32*)ustream, L.stream_words, (const u32*)tot_bits, cnt,
                        (int64_t)L.nchunks, L.nchunks);
