@@ -413,6 +413,17 @@ def main():
         extras["gaussian31x31_4k"] = {"Mpix/s": round(npx / t_b / 1e3, 1), "frames": int(sub.shape[0]),
                                       "kernel": "sepconv_mfma2_rgb_kernel (f16 matrix cores)",
                                       "roofline_frac": round(GAUSS_BYTES_PER_PX * npx / (t_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # the save step (transformation.py:161-162): one JPEG file per frame, byte-identical to Pillow's; noise frames
+        # are the encoder's worst case (0.6 bytes per pixel of entropy-coded data; photographs: ~0.1)
+        from imagetransformations_amd import jpeg
+        t_j = event_ms(lambda: jpeg.encode_device(sub16), 5)
+        _, jsz = jpeg.encode_device(sub16)
+        jbytes = float(jsz.sum().item())
+        extras["jpeg_save_q75_4k"] = {"Mpix/s": round(n16 / t_j / 1e3, 1), "files/s": round(sub16.shape[0] / t_j * 1e3, 1),
+                                      "frames": int(sub16.shape[0]), "file_bytes_per_px": round(jbytes / n16, 3),
+                                      "kernels": "jpeg_transform + jpeg_lens + scan + jpeg_emit + jpeg_ffcount + scan + jpeg_stuff",
+                                      "bound": "integer VALU (HBM: 3 bytes in + the file out per pixel)",
+                                      "roofline_frac": round((3.0 * n16 + jbytes) / (t_j * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         del sub, sub16, out
         torch.cuda.empty_cache()
         result["ops"] = extras

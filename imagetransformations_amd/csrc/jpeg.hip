@@ -326,6 +326,10 @@ __global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* __restric
         u32 run = 0;
         for (int w = 0; w < 32; ++w) {
             const u32 pair = blk[w];
+            if ((w ? pair : pair >> 16) == 0) {                  // most of a photograph's coefficients
+                run += w ? 2 : 1;
+                continue;
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (w == 0 && h == 0) continue;

@@ -2,7 +2,8 @@
 :159-162 save) as a streaming pipeline around the batched driver: JPEG decode and encode stay on
 the CPU with Pillow — the same codec the reference uses, so the pixels entering and leaving are the
 reference's — but run in worker threads (Pillow releases the GIL inside the codecs) that overlap
-with the GPU work of the neighbouring chunks:
+with the GPU work of the neighbouring chunks (`encoder="device"` moves the encode of RGB → *.jpg outputs
+to the GPU writer, `jpeg.encode`, whose files are byte-identical to Pillow's):
 
     decode chunk k+1  |  transform chunk k on the GPU  |  encode + write chunk k-1
 
@@ -40,12 +41,15 @@ def _chunks(seq: Sequence, n: int) -> Iterable[Sequence]:
 
 
 def run_directory(data_path: str, out_dir: str, chunk_images: int = 256, workers: int = 8,
-                  transform: Callable[[List[Tuple[Image.Image, str]]], List[Tuple[str, Image.Image]]] | None = None) -> int:
+                  transform: Callable[[List[Tuple[Image.Image, str]]], List[Tuple[str, Image.Image]]] | None = None,
+                  encoder: str = "pillow") -> int:
     """load_data + apply_all_transformations + save over a directory, streamed.  `transform` maps a
     chunk [(image, path)] to [(file name, image)] in output order; default: the batched
     eight-transformation driver.  Returns the number of files written."""
     if transform is None:
         from .transformation import apply_all_transformations_batched_named as transform
+    if encoder not in ("pillow", "device"):
+        raise ValueError("encoder must be 'pillow' or 'device'")
     os.makedirs(out_dir, exist_ok=True)
     chunk_paths = list(_chunks(list_images(data_path), chunk_images))
     written = 0
@@ -59,8 +63,11 @@ def run_directory(data_path: str, out_dir: str, chunk_images: int = 256, workers
             named = transform(chunk) if chunk else []
             for fut in saving:                                  # chunk k-1 has been encoding meanwhile
                 fut.result()
-            saving = [pool.submit(_save, img, os.path.join(out_dir, name)) for name, img in named]
             written += len(named)
+            saving = []
+            if encoder == "device":
+                named = _save_on_device(named, out_dir, pool, saving)
+            saving += [pool.submit(_save, img, os.path.join(out_dir, name)) for name, img in named]
         for fut in saving:
             fut.result()
     return written
@@ -68,6 +75,31 @@ def run_directory(data_path: str, out_dir: str, chunk_images: int = 256, workers
 
 def _save(img: Image.Image, path: str) -> None:
     img.save(path)                                              # Image.save defaults, as :162
+
+
+def _write(data: bytes, path: str) -> None:
+    with open(path, "wb") as f:
+        f.write(data)
+
+
+def _save_on_device(named, out_dir: str, pool, saving: list):
+    """Encode the RGB images bound for *.jpg / *.jpeg files with the GPU writer, one batch per image size (the files are
+    Pillow's, byte for byte: tests/test_gpu_jpeg.py); queue the writes on `pool`; return what is left for Pillow
+    (other modes / formats, images carrying a comment Pillow would embed)."""
+    import numpy as np
+    import torch
+    from . import jpeg
+    groups, rest = {}, []
+    for name, img in named:
+        if img.mode == "RGB" and name.lower().endswith((".jpg", ".jpeg")) and "comment" not in img.info and min(img.size) > 0:
+            groups.setdefault(img.size, []).append((name, img))
+        else:
+            rest.append((name, img))
+    for items in groups.values():
+        batch = torch.from_numpy(np.stack([np.asarray(img) for _, img in items])).cuda(non_blocking=True)
+        for (name, _), data in zip(items, jpeg.encode(batch)):
+            saving.append(pool.submit(_write, data, os.path.join(out_dir, name)))
+    return rest
 
 
 SEVERITY_INDICES = [0, 1001, 2002, 3003, 4004, 10000, 10001, 12002, 13003, 14004, 15005, 20000, 22002, 23003,

@@ -119,5 +119,8 @@ def encode(frames: torch.Tensor, quality: int = 75, capacity: int | None = None)
         if any(v == 0xFFFFFFFF for v in lens):
             raise F.ImgxfError(F.ERR_WORKSPACE, "a JPEG stream exceeds 12 bytes per pixel", "jpeg.encode")
     top = max(lens) if lens else 0
-    host = files[:, :top].cpu().numpy()
+    staged = torch.empty((n, top), dtype=torch.uint8, pin_memory=True)     # torch caches pinned blocks across calls
+    staged.copy_(files[:, :top], non_blocking=True)
+    torch.cuda.current_stream(frames.device).synchronize()
+    host = staged.numpy()
     return [host[i, :lens[i]].tobytes() for i in range(n)]

@@ -125,3 +125,29 @@ def test_argument_errors():
     with pytest.raises(ValueError):
         jpeg.encode(torch.zeros((1, 8, 8, 3), dtype=torch.float32, device="cuda"))
     assert jpeg.encode(torch.zeros((0, 8, 8, 3), dtype=torch.uint8, device="cuda")) == []
+
+
+def test_run_directory_device_encoder_writes_pillows_files(tmp_path):
+    from imagetransformations_amd import io_pipeline
+    rng = np.random.default_rng(11)
+    src = tmp_path / "in"
+    src.mkdir()
+    for i, (h, w) in enumerate([(40, 60), (40, 60), (33, 47), (64, 64), (40, 60)]):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(src / f"img{i}.jpeg", quality=95)
+
+    def transform(chunk):
+        out = []
+        for img, path in chunk:
+            stem = os.path.splitext(os.path.basename(path))[0]
+            out.append((f"{stem}_brightness_0.5_corrupted.jpg", img))
+            out.append((f"{stem}_mask.png", img.convert("L")))
+        return out
+
+    counts = {}
+    for enc in ("pillow", "device"):
+        counts[enc] = io_pipeline.run_directory(str(src), str(tmp_path / enc), chunk_images=2, workers=2, transform=transform, encoder=enc)
+    assert counts["pillow"] == counts["device"] == 10
+    names = sorted(os.listdir(tmp_path / "pillow"))
+    assert names == sorted(os.listdir(tmp_path / "device")) and len(names) == 10
+    for n in names:
+        assert (tmp_path / "pillow" / n).read_bytes() == (tmp_path / "device" / n).read_bytes(), n
