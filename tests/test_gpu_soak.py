@@ -140,3 +140,51 @@ def test_soak_full_size_equivalences(device, seed, monkeypatch):
     cl, ct, cr, cb = max(0, -tx), max(0, -ty), min(w, w - tx), min(h, h - ty)
     if cl < cr and ct < cb: ops.copy_rect(t, ref, cl, ct, max(0, tx), max(0, ty), cr - cl, cb - ct)
     assert torch.equal(T._translation_t(t, tx, ty), ref), ("translation", tx, ty)
+
+
+def _jpeg_case(rng):
+    """A random frame batch for the JPEG writer: sizes around every block / MCU boundary, contents from flat to the
+    patterns that drive the DCT and the run / size symbols to their extremes."""
+    h = int(rng.choice([1, 2, 7, 8, 9, 15, 16, 17, 31, 32, 33, int(rng.integers(1, 120))]))
+    w = int(rng.choice([1, 2, 7, 8, 9, 15, 16, 17, 31, 255, 256, 257, 272, int(rng.integers(1, 400))]))
+    n = int(rng.integers(1, 4))
+    kind = int(rng.integers(0, 8))
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == 0:
+        a = rng.integers(0, 256, (n, h, w, 3))
+    elif kind == 1:                                   # 1-px checkerboard of extremes: the largest AC magnitudes
+        a = np.broadcast_to((((yy + xx) & 1) * 255)[None, :, :, None], (n, h, w, 3))
+    elif kind == 2:                                   # binary noise
+        a = rng.integers(0, 2, (n, h, w, 3)) * 255
+    elif kind == 3:                                   # smooth gradients: long zero runs, EOB early
+        a = np.broadcast_to(((xx * int(rng.integers(1, 5)) + yy * int(rng.integers(0, 5))) % 256)[None, :, :, None], (n, h, w, 3))
+    elif kind == 4:                                   # sparse impulses: ZRL chains
+        a = np.full((n, h, w, 3), int(rng.integers(0, 256)))
+        m = rng.random((n, h, w, 1)) < 0.01
+        a = np.where(m, 255 - a, a)
+    elif kind == 5:                                   # stripes of extremes along one axis
+        a = np.broadcast_to((((xx // int(rng.integers(1, 4))) & 1) * 255)[None, :, :, None], (n, h, w, 3))
+    elif kind == 6:                                   # per-channel flats with one saturated channel
+        a = np.zeros((n, h, w, 3), np.int64)
+        a[..., int(rng.integers(0, 3))] = 255
+    else:                                             # low-amplitude noise around a level
+        a = int(rng.integers(0, 250)) + rng.integers(0, 6, (n, h, w, 3))
+    return np.ascontiguousarray(a, dtype=np.uint8), int(rng.choice([1, 5, 25, 50, 75, 75, 75, 90, 100]))
+
+
+@pytest.mark.parametrize("seed", range(max(2, SEEDS // 4)))
+def test_soak_jpeg_writer_equals_pillow(device, seed):
+    import io
+    from imagetransformations_amd import jpeg
+    rng = np.random.default_rng(770000 + seed)
+    a, quality = _jpeg_case(rng)
+    t = torch.from_numpy(a).to(device)
+    if seed % 3 == 1:                                  # a strided, unaligned view of a larger allocation
+        big = torch.zeros((a.shape[0], a.shape[1] + 3, a.shape[2] + 5, 3), dtype=torch.uint8, device=device)
+        big[:, 2:2 + a.shape[1], 1:1 + a.shape[2]] = t
+        t = big[:, 2:2 + a.shape[1], 1:1 + a.shape[2]]
+    files = jpeg.encode(t, quality)
+    for i in range(a.shape[0]):
+        buf = io.BytesIO()
+        Image.fromarray(a[i]).save(buf, "JPEG", quality=quality)
+        assert files[i] == buf.getvalue(), (seed, i, a.shape, quality)
