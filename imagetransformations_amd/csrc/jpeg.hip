@@ -82,8 +82,8 @@ constexpr int zz(int i) {
 // One workgroup: rows y0 .. y0+15, columns x0 .. x0+255 of frame f.  128 threads: both waves stage and convert, then
 // wave 0 transforms the 64 luminance blocks and the lower half of wave 1 the 32 chrominance blocks.
 __global__ __launch_bounds__(128) void jpeg_transform_kernel(View s, int16_t* __restrict__ coef, int64_t coef_fs,
-                                                             int16_t* __restrict__ dcs, uint16_t* __restrict__ acbits, int mw,
-                                                             int bw, int bh, JpegQuant q) {
+                                                             int16_t* __restrict__ dcs, uint16_t* __restrict__ acbits, int nblk,
+                                                             int mw, int bw, int bh, JpegQuant q) {
     __shared__ __attribute__((aligned(4))) u8 slen[2][256];
     __shared__ __attribute__((aligned(16))) u8 rgb[16][768];
     __shared__ __attribute__((aligned(16))) u8 yp[16][256 + 8];
@@ -201,10 +201,13 @@ __global__ __launch_bounds__(128) void jpeg_transform_kernel(View s, int16_t* __
             run = a ? 0u : run + 1;
         }
         if (run) bits += lt[0];
-        acbits[(int64_t)f * (coef_fs / 64) + blk] = (uint16_t)bits;
-        dcs[(int64_t)f * (coef_fs / 64) + blk] = (int16_t)d[0];
+        acbits[(int64_t)f * nblk + blk] = (uint16_t)bits;
+        dcs[(int64_t)f * nblk + blk] = (int16_t)d[0];
     }
-    uint4* out = (uint4*)(coef + (int64_t)f * coef_fs + blk * 64);
+    // zigzag order, eight coefficients (16 bytes) at a time, interleaved over groups of 64 blocks: piece g of block b
+    // at 16-byte slot (b >> 6)·512 + g·64 + (b & 63), so that the emit kernel's one-thread-per-block walk reads
+    // consecutive 16-byte pieces across a wave
+    uint4* out = (uint4*)(coef + (int64_t)f * coef_fs) + (blk >> 6) * 512 + (blk & 63);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         uint4 v;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(128) void jpeg_transform_kernel(View s, int16_t* __
         v.y = (u32)(d[zz(g * 8 + 2)] & 0xffff) | ((u32)d[zz(g * 8 + 3)] << 16);
         v.z = (u32)(d[zz(g * 8 + 4)] & 0xffff) | ((u32)d[zz(g * 8 + 5)] << 16);
         v.w = (u32)(d[zz(g * 8 + 6)] & 0xffff) | ((u32)d[zz(g * 8 + 7)] << 16);
-        out[g] = v;
+        out[g * 64] = v;
     }
 }
 
@@ -263,35 +266,34 @@ __global__ __launch_bounds__(256) void jpeg_lens_kernel(const int16_t* __restric
     lens[(int64_t)f * g.nblk + j] = (hf.dc[t][cat] >> 16) + cat + (dummy ? hf.ac[t][0] >> 16 : (u32)acbits[(int64_t)f * g.nblk + j]);
 }
 
-// 256 blocks per workgroup: their 32 KB of coefficients are staged through LDS with coalesced loads (row stride 33
-// dwords, so that the per-thread walks below hit different banks), then every thread emits its block's codes at the
-// block's bit offset: the first word it touches is shared with the previous block (atomic OR), the words after it are
-// its own (plain stores), the last partial word is shared with the next block (atomic OR).
+// One thread per block: the coefficients come interleaved over 64 blocks (see jpeg_transform_kernel), so a wave's
+// loads are consecutive dwords; every thread walks its block and writes the codes MSB-first at the block's bit offset:
+// the first word it touches is shared with the previous block (atomic OR), the words after it are its own (plain
+// stores), the last partial word is shared with the next block (atomic OR).
 __global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* __restrict__ coef, int64_t coef_fs, const int16_t* __restrict__ dcs,
                                                         const u32* __restrict__ offs, u32* __restrict__ stream, int64_t stream_fs_words,
                                                         const u32* __restrict__ total_bits, JpegGeom g, JpegHuff hf) {
+    constexpr u32 LW = 4096;                                  // words of the workgroup's span merged in LDS (16 KB)
     __shared__ u32 sdc[2][16];
     __shared__ u32 sac[2][256];
-    __shared__ u32 sco[256 * 33];
+    __shared__ u32 lbuf[LW];
     const int f = blockIdx.y, j0 = blockIdx.x * 256, j = j0 + threadIdx.x;
     if (((unsigned long long)total_bits[f] + 31) / 32 > (unsigned long long)stream_fs_words) return;   // reported by jpeg_stuff_kernel
     for (int i = threadIdx.x; i < 32; i += 256) sdc[i >> 4][i & 15] = hf.dc[i >> 4][i & 15];
     for (int i = threadIdx.x; i < 512; i += 256) sac[i >> 8][i & 255] = hf.ac[i >> 8][i & 255];
-    {
-        const uint4* src = (const uint4*)(coef + (int64_t)f * coef_fs + (int64_t)j0 * 64);
-        const int nv = min(256, g.nblk - j0) * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = threadIdx.x + 256 * i;
-            if (idx < nv) {
-                const uint4 v = src[idx];
-                u32* dst = &sco[(idx >> 3) * 33 + (idx & 7) * 4];
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-            }
-        }
-    }
+    // the bits of this workgroup's 256 blocks are contiguous: [offs[j0], offs[j0 + 256]).  When that span fits LW words
+    // the codes are merged in LDS (ds_or) and leave as coalesced stores, with global atomics only on the two words
+    // shared with the neighbouring workgroups; longer spans (≈ > 500 bits per block) write to the stream directly.
+    const int j1 = min(j0 + 256, g.nblk);
+    const u32 sbit = offs[(int64_t)f * g.nblk + j0];
+    const u32 ebit = j1 < g.nblk ? offs[(int64_t)f * g.nblk + j1] : total_bits[f];
+    const u32 wlo = sbit >> 5, nw = ((ebit + 31) >> 5) - wlo;
+    const bool merged = nw <= LW;
+    if (merged)
+        for (u32 i = threadIdx.x; i < nw; i += 256) lbuf[i] = 0;
     __syncthreads();
-    if (j >= g.nblk) return;
+    u32* gs = stream + (int64_t)f * stream_fs_words;
+    if (j < g.nblk) {
     const int mcu = j / 6, k = j - mcu * 6, my = mcu / g.mw, mx = mcu - my * g.mw;
     const int16_t* dd = dcs + (int64_t)f * g.nblk;
     bool dummy;
@@ -300,16 +302,17 @@ __global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* __restric
     const u32 off = offs[(int64_t)f * g.nblk + j];
     unsigned long long acc = 0;
     u32 nb = off & 31;
-    u32* wp = stream + (int64_t)f * stream_fs_words + (off >> 5);
+    u32 wi = off >> 5;
     bool first = true;
     auto put = [&](u32 code, u32 len) {
         acc |= (unsigned long long)code << (64 - nb - len);
         nb += len;
         if (nb >= 32) {
-            if (first) atomicOr(wp, (u32)(acc >> 32));
-            else *wp = (u32)(acc >> 32);
+            if (merged) atomicOr(&lbuf[wi - wlo], (u32)(acc >> 32));
+            else if (first) atomicOr(gs + wi, (u32)(acc >> 32));
+            else gs[wi] = (u32)(acc >> 32);
             first = false;
-            ++wp;
+            ++wi;
             acc <<= 32;
             nb -= 32;
         }
@@ -321,29 +324,37 @@ __global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* __restric
         put(((e & 0xffff) << cat) | ((u32)(diff + sg) & ((1u << cat) - 1)), (e >> 16) + cat);
     }
     if (!dummy) {
-        const u32* blk = &sco[threadIdx.x * 33];
+        const uint4* blk = (const uint4*)(coef + (int64_t)f * coef_fs) + (j >> 6) * 512 + (j & 63);
         const u32 zrl = sac[t][0xF0];
         u32 run = 0;
-        for (int w = 0; w < 32; ++w) {
-            const u32 pair = blk[w];
-            if ((w ? pair : pair >> 16) == 0) {                  // most of a photograph's coefficients
-                run += w ? 2 : 1;
-                continue;
-            }
+        uint4 nxt = blk[0];
+        for (int g8 = 0; g8 < 8; ++g8) {
+            const uint4 cur = nxt;
+            if (g8 < 7) nxt = blk[(g8 + 1) * 64];
+            const u32 pairs[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (w == 0 && h == 0) continue;
-                const int c = (int)(int16_t)(pair >> (16 * h));
-                if (c == 0) {
-                    ++run;
+            for (int u = 0; u < 4; ++u) {
+                const u32 pair = pairs[u];
+                const bool dcpair = g8 == 0 && u == 0;
+                if ((dcpair ? pair >> 16 : pair) == 0) {          // most of a photograph's coefficients
+                    run += dcpair ? 1 : 2;
                     continue;
                 }
-                for (u32 z = run >> 4; z > 0; --z) put(zrl & 0xffff, zrl >> 16);
-                const int sg = c >> 31;
-                const u32 cat = 32 - (u32)__clz((c ^ sg) - sg);
-                const u32 e = sac[t][((run & 15) << 4) | cat];
-                put(((e & 0xffff) << cat) | ((u32)(c + sg) & ((1u << cat) - 1)), (e >> 16) + cat);
-                run = 0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (dcpair && h == 0) continue;
+                    const int c = (int)(int16_t)(pair >> (16 * h));
+                    if (c == 0) {
+                        ++run;
+                        continue;
+                    }
+                    for (u32 z = run >> 4; z > 0; --z) put(zrl & 0xffff, zrl >> 16);
+                    const int sg = c >> 31;
+                    const u32 cat = 32 - (u32)__clz((c ^ sg) - sg);
+                    const u32 e = sac[t][((run & 15) << 4) | cat];
+                    put(((e & 0xffff) << cat) | ((u32)(c + sg) & ((1u << cat) - 1)), (e >> 16) + cat);
+                    run = 0;
+                }
             }
         }
         if (run) {
@@ -354,7 +365,22 @@ __global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* __restric
         const u32 e = sac[t][0];
         put(e & 0xffff, e >> 16);
     }
-    if (nb) atomicOr(wp, (u32)(acc >> 32));
+    if (nb) {
+        if (merged) atomicOr(&lbuf[wi - wlo], (u32)(acc >> 32));
+        else atomicOr(gs + wi, (u32)(acc >> 32));
+    }
+    }
+    if (merged) {
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < nw; i += 256) {
+            const u32 v = lbuf[i];
+            if (i == 0 || i + 1 == nw) {
+                if (v) atomicOr(gs + wlo + i, v);
+            } else {
+                gs[wlo + i] = v;
+            }
+        }
+    }
 }
 
 // ---- exclusive scan of u32 rows (in place), 1024 elements per workgroup ---------------------------------------------
@@ -525,7 +551,7 @@ static JpegLayout jpeg_layout(int n, int h, int w, size_t out_frame_stride) {
     L.nchunks = (int)((L.stream_words * 4 + JCHUNK - 1) / JCHUNK);
     L.nparts_chunk = (L.nchunks + 1023) / 1024;
     size_t o = 0;
-    L.off_coef = o;   o += al256((size_t)n * L.nblk * 128);
+    L.off_coef = o;   o += al256((size_t)n * (size_t)((L.nblk + 63) / 64) * 64 * 128);
     L.off_dcs = o;    o += al256((size_t)n * L.nblk * 2);
     L.off_acb = o;    o += al256((size_t)n * L.nblk * 2);
     L.off_lens = o;   o += al256((size_t)n * L.nblk * 4);
@@ -617,9 +643,9 @@ IMGXF_API int imgxf_jpeg_encode_u8(const imgxf_view* src, const imgxf_jpeg_table
     u32* ustream = (u32*)(ws + L.off_stream);
     u32* cnt = (u32*)(ws + L.off_cnt);
     const JpegGeom g = {L.mw, L.mh, L.bw, L.bh, L.nblk};
-    const int64_t coef_fs = (int64_t)L.nblk * 64;
+    const int64_t coef_fs = (int64_t)((L.nblk + 63) / 64) * 64 * 64;          // int16 elements per frame, whole groups of 64 blocks
     hipLaunchKernelGGL(jpeg_transform_kernel, dim3((unsigned)((L.mw + JM - 1) / JM), (unsigned)L.mh, (unsigned)s.n), dim3(128), 0, st,
-                       s, coef, coef_fs, dcs, acb, L.mw, L.bw, L.bh, q);
+                       s, coef, coef_fs, dcs, acb, L.nblk, L.mw, L.bw, L.bh, q);
     const dim3 bgrid((unsigned)((L.nblk + 255) / 256), (unsigned)s.n);
     hipLaunchKernelGGL(jpeg_lens_kernel, bgrid, dim3(256), 0, st, (const int16_t*)dcs, (const uint16_t*)acb, lens, g, hf);
     IMGXF_CHECK(scan_rows(lens, L.nblk, L.nblk, s.n, part, tot_bits, st));
