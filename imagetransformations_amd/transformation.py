@@ -260,6 +260,23 @@ def plan_transformations(name: str):
     return plan
 
 
+JPEG_ON_DEVICE = os.environ.get("IMGXF_JPEG_DEVICE", "0") == "1"
+
+
+def save_image(img: Image.Image, path: str) -> None:
+    """The reference's `transformed.save(path)` (:161-162).  With `JPEG_ON_DEVICE` (or IMGXF_JPEG_DEVICE=1) an RGB image
+    bound for a *.jpg / *.jpeg file is encoded by the GPU writer (`jpeg.encode`: the file Pillow would write, byte for
+    byte); every other mode / format, and images carrying a comment Pillow would embed, go through Pillow."""
+    if (JPEG_ON_DEVICE and img.mode == "RGB" and path.lower().endswith((".jpg", ".jpeg")) and "comment" not in img.info
+            and min(img.size) > 0):
+        from . import jpeg
+        data = jpeg.encode(_upload(img)[None])[0]
+        with open(path, "wb") as f:
+            f.write(data)
+    else:
+        img.save(path)
+
+
 def apply_all_transformations(images):
     """images: [(PIL image, path)] -> list of transformed PIL images (8 per input)."""
     transformed_images = []
@@ -270,7 +287,7 @@ def apply_all_transformations(images):
             fn = apply_translation if transform_type == 'translation' else _DISPATCH[transform_type]
             transformed_img = fn(img, *args)
             if output_dir is not None:
-                transformed_img.save(os.path.join(output_dir, new_filename))
+                save_image(transformed_img, os.path.join(output_dir, new_filename))
             transformed_images.append(transformed_img)
             total_transforms += 1
         if (i + 1) % 1000 == 0:
@@ -283,7 +300,7 @@ def apply_all_transformations_batched(images):
     transformed_images = []
     for new_filename, img in apply_all_transformations_batched_named(images):
         if output_dir is not None:
-            img.save(os.path.join(output_dir, new_filename))
+            save_image(img, os.path.join(output_dir, new_filename))
         transformed_images.append(img)
     return transformed_images
 
