@@ -22,9 +22,9 @@ constexpr int JT = 128;                      // threads (>= 6·JM blocks; 32 MCU
 constexpr int JPX = 16 * JM;                 // pixels per row of the workgroup's strip
 constexpr int JCHUNK = 32;                   // bytes per stuffing thread
 
-struct JpegQuant {                           // per coefficient (natural order): |c| → ((|c| + half) · m) >> 32
-    u32 m[2][64];                            // ceil(2^32 / 8q)
-    u32 half[2][64];                         // 4q
+struct JpegQuant {                           // per coefficient (natural order): |c| → (((|c| + half) << sh) · m) >> 32, 24-bit operands
+    u32 m[2][64];                            // ceil(2^32 / (8q << sh)) < 2^24, sh = the shift that brings 8q above 256
+    u32 half[2][64];                         // 4q | sh << 16
     u8 aclen[2][256];                        // Huffman code length of the AC symbol (run << 4) | size
 };
 struct JpegHuff {                            // code | len << 16
@@ -189,7 +189,9 @@ __global__ __launch_bounds__(JT) void jpeg_transform_kernel(View s, int16_t* __r
     for (int i = 0; i < 64; ++i) {                                // jcdctmgr.c quantize: sign · ((|c| + 4q) / 8q)
         const int v = d[i], sg = v >> 31;
         const u32 a = (u32)((v ^ sg) - sg);
-        const u32 qq = __umulhi(a + q.half[chroma][i], q.m[chroma][i]);
+        const u32 hs = q.half[chroma][i];
+        const u32 x = (a + (hs & 0xffff)) << (hs >> 16);         // < 2^23
+        const u32 qq = (u32)(((unsigned long long)(x & 0xffffffu) * (q.m[chroma][i] & 0xffffffu)) >> 32);   // v_mul_hi_u32_u24: full rate
         d[i] = ((int)qq ^ sg) - sg;
     }
     const int64_t blk = ((int64_t)my * mw + mx0 + ml) * 6 + k;
@@ -574,17 +576,23 @@ static JpegLayout jpeg_layout(int n, int h, int w, size_t out_frame_stride) {
 
 // exact for every |c| the DCT can produce (checked over 0 .. 65535 here): floor((a + d/2) / d), d = 8q
 struct QuantMagic {
-    u32 m[256];
+    u32 m[256], sh[256];
     bool ok[256];
     QuantMagic() {
         for (u32 qv = 1; qv < 256; ++qv) {
             const u32 d = qv * 8, half = d >> 1;
-            m[qv] = (u32)(((1ull << 32) + d - 1) / d);
-            ok[qv] = true;
-            for (u32 a = 0; a < 65536 && ok[qv]; ++a)
-                ok[qv] = (a + half) / d == (u32)(((unsigned long long)(a + half) * m[qv]) >> 32);
+            u32 s = 0;
+            while ((d << s) <= 256) ++s;
+            const u32 dd = d << s;
+            m[qv] = (u32)(((1ull << 32) + dd - 1) / dd);
+            sh[qv] = s;
+            ok[qv] = m[qv] < (1u << 24);
+            for (u32 a = 0; a < 65536 && ok[qv]; ++a) {
+                const u32 x = (a + half) << s;
+                ok[qv] = x < (1u << 24) && (a + half) / d == (u32)(((unsigned long long)x * m[qv]) >> 32);
+            }
         }
-        m[0] = 0;
+        m[0] = sh[0] = 0;
         ok[0] = false;
     }
 };
@@ -592,7 +600,7 @@ static bool quant_entry(u32 qv, u32* m, u32* halfp) {
     static const QuantMagic magic;                          // built (and checked) once per process
     if (qv > 255 || !magic.ok[qv]) return false;
     *m = magic.m[qv];
-    *halfp = qv * 4;
+    *halfp = (qv * 4) | (magic.sh[qv] << 16);
     return true;
 }
 
