@@ -118,9 +118,12 @@ def encode(frames: torch.Tensor, quality: int = 75, capacity: int | None = None)
         lens = sizes.cpu().tolist()
         if any(v == 0xFFFFFFFF for v in lens):
             raise F.ImgxfError(F.ERR_WORKSPACE, "a JPEG stream exceeds 12 bytes per pixel", "jpeg.encode")
-    top = max(lens) if lens else 0
-    staged = torch.empty((n, top), dtype=torch.uint8, pin_memory=True)     # torch caches pinned blocks across calls
-    staged.copy_(files[:, :top], non_blocking=True)
+    starts = [0]
+    for v in lens:
+        starts.append(starts[-1] + ((v + 63) & ~63))
+    staged = torch.empty((starts[-1],), dtype=torch.uint8, pin_memory=True)   # torch caches pinned blocks across calls
+    for i, v in enumerate(lens):                                               # exact-size, contiguous DMA copies
+        staged[starts[i]:starts[i] + v].copy_(files[i, :v], non_blocking=True)
     torch.cuda.current_stream(frames.device).synchronize()
     host = staged.numpy()
-    return [host[i, :lens[i]].tobytes() for i in range(n)]
+    return [host[starts[i]:starts[i] + lens[i]].tobytes() for i in range(n)]
