@@ -46,8 +46,10 @@ def run_directory(data_path: str, out_dir: str, chunk_images: int = 256, workers
     """load_data + apply_all_transformations + save over a directory, streamed.  `transform` maps a
     chunk [(image, path)] to [(file name, image)] in output order; default: the batched
     eight-transformation driver.  Returns the number of files written."""
+    device_driver = transform is None and encoder == "device"
     if transform is None:
         from .transformation import apply_all_transformations_batched_named as transform
+        from .transformation import apply_all_transformations_batched_to_files as to_files
     if encoder not in ("pillow", "device"):
         raise ValueError("encoder must be 'pillow' or 'device'")
     os.makedirs(out_dir, exist_ok=True)
@@ -60,6 +62,12 @@ def run_directory(data_path: str, out_dir: str, chunk_images: int = 256, workers
             chunk = [d for d in decoding if d is not None]
             if k + 1 < len(chunk_paths):                        # the next chunk decodes while this one is on the GPU
                 decoding = pool.map(_decode, chunk_paths[k + 1])
+            if device_driver:                                   # transforms + JPEG writer, nothing but the files comes back
+                for fut in saving:
+                    fut.result()
+                saving = []
+                written += len(to_files(chunk, out_dir)) if chunk else 0
+                continue
             named = transform(chunk) if chunk else []
             for fut in saving:                                  # chunk k-1 has been encoding meanwhile
                 fut.result()

@@ -305,13 +305,41 @@ def apply_all_transformations_batched(images):
     return transformed_images
 
 
-def apply_all_transformations_batched_named(images):
+def apply_all_transformations_batched_to_files(images, out_dir: str) -> List[str]:
+    """The batched driver with the save step (:159-162) on the device too: every group's result goes from the transform
+    kernels straight into the JPEG writer (`jpeg.encode`), and only the files — a tenth of a byte per pixel for
+    photographs instead of three — cross PCIe.  Same draws, names, order and FILES as `apply_all_transformations_batched`
+    with `output_dir` set (Pillow's encoder): tests/test_gpu_jpeg.py.  Returns the file names in output order."""
+    from . import jpeg
+    os.makedirs(out_dir, exist_ok=True)
+
+    def sink(out: torch.Tensor, names: List[str]) -> None:
+        on_device = [n.lower().endswith((".jpg", ".jpeg")) for n in names]
+        if all(on_device) and out.dim() == 4 and out.shape[-1] == 3:
+            for name, data in zip(names, jpeg.encode(out)):
+                with open(os.path.join(out_dir, name), "wb") as f:
+                    f.write(data)
+        else:                                             # another format: Pillow writes it
+            host = staging.download(out).numpy()
+            for j, name in enumerate(names):
+                Image.fromarray(host[j]).save(os.path.join(out_dir, name))
+
+    named = apply_all_transformations_batched_named(images, _sink=sink)
+    for name, img in named:
+        if img is not None:                               # per-image path (not RGB) or apply_blur's radius-0 pass-through
+            save_image(img, os.path.join(out_dir, name))
+    return [name for name, _ in named]
+
+
+def apply_all_transformations_batched_named(images, _sink=None):
     """`apply_all_transformations` with the work grouped for the GPU, returning
     [(file name, image)] in the reference's output order and saving nothing: same draws (`random` per
     transform type per image, `np.random` for the noise, in the reference's order), same file
     names, same outputs in the same order — but every image is uploaded once, and all images
     of one size that drew the same (type, value) go through ONE batched launch.  Images that
-    are not 8-bit RGB take the per-image path.  images: [(PIL image, path)]."""
+    are not 8-bit RGB take the per-image path.  images: [(PIL image, path)].  `_sink(out, names)`, when given,
+    consumes a group's result ON THE DEVICE ([B, H, W, 3] tensor + its file names) instead of it being copied back:
+    those entries come back as (file name, None)."""
     dev = _device()
     plans, noise = [], {}
     for i, (img, path) in enumerate(images):
@@ -365,6 +393,9 @@ def apply_all_transformations_batched_named(images):
                 out = ops.add_noise(batch, z)
             else:
                 out = tensor_fns[transform_type](batch, *args)
+            if _sink is not None:
+                _sink(out, [plans[i][k][2] for _, i, k in entries])
+                continue
             # queue the copy back and keep launching: the host waits per result only when it builds the images
             pending.append((staging.download(out), entries))
     for dl, entries in pending:

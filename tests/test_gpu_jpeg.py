@@ -196,3 +196,26 @@ def test_c_abi_argument_checks():
     assert run(t, tables=bad) == F.ERR_ARG
     with pytest.raises(ValueError):
         F.call("imgxf_jpeg_workspace_bytes", 1, 0, 16, 4096, ctypes.byref(need))
+
+
+def test_batched_driver_with_the_save_step_on_the_device(tmp_path, monkeypatch):
+    """apply_all_transformations_batched_to_files == apply_all_transformations_batched + Pillow's save: same names, same
+    files, for the same `random` / `np.random` seeds (mixed sizes; seeds that draw a radius-0 blur included)."""
+    import random
+    from imagetransformations_amd import transformation as T
+    rng = np.random.default_rng(21)
+    imgs = [(Image.fromarray(rng.integers(0, 256, hw + (3,), dtype=np.uint8)), f"/data/n0{i}/img_{i}.JPEG")
+            for i, hw in enumerate([(32, 32), (48, 64), (32, 32), (37, 61), (48, 64)])]
+    for seed in (0, 1, 2, 3):
+        ref_dir, dev_dir = tmp_path / f"pillow{seed}", tmp_path / f"device{seed}"
+        ref_dir.mkdir()
+        monkeypatch.setattr(T, "output_dir", str(ref_dir))
+        random.seed(seed); np.random.seed(seed)
+        T.apply_all_transformations_batched(imgs)
+        monkeypatch.setattr(T, "output_dir", None)
+        random.seed(seed); np.random.seed(seed)
+        names = T.apply_all_transformations_batched_to_files(imgs, str(dev_dir))
+        assert len(names) == 8 * len(imgs)
+        assert sorted(os.listdir(ref_dir)) == sorted(os.listdir(dev_dir)) == sorted(set(names))
+        for n in set(names):
+            assert (ref_dir / n).read_bytes() == (dev_dir / n).read_bytes(), (seed, n)

@@ -19,3 +19,29 @@ for name, fn in (("per-image", T.apply_all_transformations), ("batched", T.apply
     out = fn(imgs)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"{name:10s} {n} images {h}x{w}: {dt:7.3f} s  {n / dt:9.1f} images/s  ({8 * n / dt:9.1f} transforms/s)", flush=True)
+
+# with the save step (transformation.py:159-162): Pillow's encoder on the results copied back vs the device writer
+import shutil, tempfile
+if os.environ.get("SAVE", "1") == "1":
+    photo = os.environ.get("KIND", "photo") == "photo"
+    if photo:       # smooth content compresses like photographs; the noise images above are the encoder's worst case
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = 128 + 60 * np.sin(xx / 37.0) + 50 * np.cos(yy / 29.0)
+        imgs = [(Image.fromarray(np.clip(base[..., None] + 10 * (i % 7) + rng.normal(0, 5, (h, w, 3)), 0, 255).astype(np.uint8)),
+                 f"img_{i}.jpeg") for i in range(n)]
+    for name in ("batched + Pillow save", "batched, save on device"):
+        d = tempfile.mkdtemp(prefix="imgxf_bench_")
+        try:
+            random.seed(0); np.random.seed(0)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            if name.endswith("device"):
+                T.apply_all_transformations_batched_to_files(imgs, d)
+            else:
+                T.output_dir = d
+                T.apply_all_transformations_batched(imgs)
+                T.output_dir = None
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            nfiles = len(os.listdir(d))
+            print(f"{name:24s} {n} images {h}x{w}: {dt:7.3f} s  {n / dt:9.1f} images/s  ({nfiles} files, {nfiles / dt:9.1f} files/s)", flush=True)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
