@@ -219,3 +219,23 @@ def test_batched_driver_with_the_save_step_on_the_device(tmp_path, monkeypatch):
         assert sorted(os.listdir(ref_dir)) == sorted(os.listdir(dev_dir)) == sorted(set(names))
         for n in set(names):
             assert (ref_dir / n).read_bytes() == (dev_dir / n).read_bytes(), (seed, n)
+
+
+def test_run_directory_default_driver_device_encoder(tmp_path):
+    """The whole on-disk loop (load_data → eight transforms per image → save) with the save step on the device writes
+    the files the Pillow-encoder pipeline writes."""
+    import random
+    from imagetransformations_amd import io_pipeline
+    rng = np.random.default_rng(31)
+    src = tmp_path / "in"
+    src.mkdir()
+    for i, (h, w) in enumerate([(40, 60), (40, 60), (33, 47), (40, 60), (64, 64)]):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(src / f"img{i}.jpeg", quality=92)
+    for enc in ("pillow", "device"):
+        random.seed(5); np.random.seed(5)
+        n = io_pipeline.run_directory(str(src), str(tmp_path / enc), chunk_images=2, workers=2, encoder=enc)
+        assert n == 40
+    names = sorted(os.listdir(tmp_path / "pillow"))
+    assert names == sorted(os.listdir(tmp_path / "device"))
+    for n in names:
+        assert (tmp_path / "pillow" / n).read_bytes() == (tmp_path / "device" / n).read_bytes(), n
