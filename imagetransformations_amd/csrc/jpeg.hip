@@ -483,11 +483,33 @@ __global__ __launch_bounds__(256) void jpeg_zero_kernel(u32* __restrict__ stream
     else for (int e = 0; i + e < fs_words; ++e) p[e] = 0;
 }
 
-// byte i of frame f's unstuffed stream (MSB-first words); the last byte is completed with 1-bits (jchuff.c flush_bits)
-__device__ __forceinline__ u32 stream_byte(const u32* w, int64_t i, u32 tbits) {
-    u32 b = (w[i >> 2] >> (24 - 8 * (int)(i & 3))) & 255;
-    if ((u32)i == (tbits >> 3) && (tbits & 7)) b |= (1u << (8 - (tbits & 7))) - 1;
-    return b;
+// The eight MSB-first words of chunk ci of a frame's unstuffed stream, bytes past the end cleared and the last byte
+// completed with 1-bits (jchuff.c flush_bits).
+__device__ __forceinline__ void chunk_words(const u32* __restrict__ w, int ci, int64_t nbytes, u32 tb, u32 (&ws)[8]) {
+    const uint4 a = ((const uint4*)w)[ci * 2], b = ((const uint4*)w)[ci * 2 + 1];
+    ws[0] = a.x; ws[1] = a.y; ws[2] = a.z; ws[3] = a.w;
+    ws[4] = b.x; ws[5] = b.y; ws[6] = b.z; ws[7] = b.w;
+    const int64_t left = nbytes - (int64_t)ci * JCHUNK;           // > 0
+    if (left < JCHUNK) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int v = (int)left - 4 * e;                       // valid bytes of word e
+            ws[e] = v >= 4 ? ws[e] : (v <= 0 ? 0u : ws[e] & (0xffffffffu << (32 - 8 * v)));
+        }
+    }
+    if ((tb & 7) && left <= JCHUNK) {                              // the stream's last byte lives in this chunk
+        const int lb = (int)left - 1;
+        const u32 pad = ((1u << (8 - (tb & 7))) - 1) << (24 - 8 * (lb & 3));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ws[e] |= (e == (lb >> 2)) ? pad : 0u;
+    }
+}
+
+__device__ __forceinline__ u32 ff_bytes(u32 w) {                  // number of 0xFF bytes in a word
+    u32 t = w & (w >> 4) & 0x0f0f0f0fu;
+    t &= t >> 2;
+    t &= t >> 1;
+    return __popc(t & 0x01010101u);
 }
 
 __global__ __launch_bounds__(256) void jpeg_ffcount_kernel(const u32* __restrict__ stream, int64_t fs_words, const u32* __restrict__ total_bits,
@@ -499,23 +521,30 @@ __global__ __launch_bounds__(256) void jpeg_ffcount_kernel(const u32* __restrict
     const u32* w = stream + (int64_t)f * fs_words;
     for (int ci = blockIdx.x * 256 + threadIdx.x; ci < nchunks; ci += gridDim.x * 256) {   // the capacity, mostly unused
         u32 c = 0;
-        const int64_t b0 = (int64_t)ci * JCHUNK;
-        if (b0 < nbytes)
-            for (int e = 0; e < JCHUNK; ++e)
-                if (b0 + e < nbytes) c += stream_byte(w, b0 + e, tb) == 255;
+        if ((int64_t)ci * JCHUNK < nbytes) {
+            u32 ws[8];
+            chunk_words(w, ci, nbytes, tb, ws);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c += ff_bytes(ws[e]);
+        }
         cnt[(int64_t)f * cnt_fs + ci] = c;
     }
 }
 
+// 256 chunks (8 KB of stream) per workgroup pass: every thread expands its chunk into LDS at its stuffed offset (byte
+// writes), then the workgroup copies its contiguous piece of the file out — whole dwords where the piece covers them,
+// single bytes at its two ends (the neighbouring workgroups own the rest of those dwords).
 __global__ __launch_bounds__(256) void jpeg_stuff_kernel(const u32* __restrict__ stream, int64_t fs_words, const u32* __restrict__ total_bits,
                                                          const u32* __restrict__ cnt, int64_t cnt_fs, int nchunks,
                                                          const u32* __restrict__ ff_total, u8* __restrict__ out, int64_t out_fs,
                                                          u32* __restrict__ sizes, JpegHeader hd) {
+    __shared__ __attribute__((aligned(4))) u8 lb[256 * 2 * JCHUNK + 8];
     const int f = blockIdx.y;
     const u32 tb = total_bits[f];
     const bool over = ((unsigned long long)tb + 31) / 32 > (unsigned long long)fs_words;
     const int64_t nbytes = ((int64_t)tb + 7) >> 3;
-    const int64_t fsize = (int64_t)hd.len + nbytes + ff_total[f] + 2;
+    const u32 nff = ff_total[f];
+    const int64_t fsize = (int64_t)hd.len + nbytes + nff + 2;
     const bool fits = !over && fsize <= out_fs;
     u8* o = out + (int64_t)f * out_fs;
     if (blockIdx.x == 0) {
@@ -530,15 +559,42 @@ __global__ __launch_bounds__(256) void jpeg_stuff_kernel(const u32* __restrict__
     }
     if (!fits) return;
     const u32* w = stream + (int64_t)f * fs_words;
-    for (int ci = blockIdx.x * 256 + threadIdx.x; ci < nchunks; ci += gridDim.x * 256) {
-        const int64_t b0 = (int64_t)ci * JCHUNK;
-        if (b0 >= nbytes) break;
-        u8* p = o + hd.len + b0 + cnt[(int64_t)f * cnt_fs + ci];
-        for (int e = 0; e < JCHUNK && b0 + e < nbytes; ++e) {
-            const u32 b = stream_byte(w, b0 + e, tb);
-            *p++ = (u8)b;
-            if (b == 255) *p++ = 0;
+    const u32* cf = cnt + (int64_t)f * cnt_fs;
+    const int nvc = (int)((nbytes + JCHUNK - 1) / JCHUNK);         // chunks that hold stream bytes
+    for (int c0 = blockIdx.x * 256; c0 < nvc; c0 += gridDim.x * 256) {
+        const int ce = min(c0 + 256, nvc);
+        const u32 pre0 = cf[c0];
+        const u32 pre1 = ce < nchunks ? cf[ce] : nff;
+        u8* dst = o + hd.len + (int64_t)c0 * JCHUNK + pre0;        // where this pass's piece of the file starts
+        const u32 mis = (u32)((uintptr_t)dst & 3);
+        const u32 total = (u32)(min((int64_t)ce * JCHUNK, nbytes) - (int64_t)c0 * JCHUNK) + (pre1 - pre0);
+        const int ci = c0 + threadIdx.x;
+        if (ci < ce) {
+            u32 ws[8];
+            chunk_words(w, ci, nbytes, tb, ws);
+            const int nv = (int)min((int64_t)JCHUNK, nbytes - (int64_t)ci * JCHUNK);
+            u8* p = lb + mis + threadIdx.x * JCHUNK + (cf[ci] - pre0);
+#pragma unroll
+            for (int e = 0; e < JCHUNK; ++e) {
+                if (e < nv) {
+                    const u32 b = (ws[e >> 2] >> (24 - 8 * (e & 3))) & 255;
+                    *p++ = (u8)b;
+                    if (b == 255) *p++ = 0;
+                }
+            }
         }
+        __syncthreads();
+        u8* base = dst - mis;                                      // 4-byte aligned, LDS byte k ↔ base[k]
+        const u32 end = mis + total;
+        for (u32 k = threadIdx.x * 4; k < end; k += 1024) {
+            if (k >= mis && k + 4 <= end) {
+                *(u32*)(base + k) = *(const u32*)(lb + k);
+            } else {
+                for (u32 e = 0; e < 4; ++e)
+                    if (k + e >= mis && k + e < end) base[k + e] = lb[k + e];
+            }
+        }
+        __syncthreads();
     }
 }
 
