@@ -318,7 +318,9 @@ typedef struct imgxf_jpeg_tables {
  * the entropy-coded segment, EOI; sizes[f] (device) = the file's length, or 0xFFFFFFFF when it
  * does not fit in out_frame_stride bytes (nothing usable is written for that frame).
  * Bit-identical to libjpeg(-turbo)'s output for the same tables.  workspace: device, 16-byte
- * aligned, >= imgxf_jpeg_workspace_bytes(n, h, w, out_frame_stride). */
+ * aligned, >= imgxf_jpeg_workspace_bytes(n, h, w, out_frame_stride).  Limits: n <= 65535,
+ * out_frame_stride <= 2^31, ceil(w/16)*ceil(h/16) < 349525 MCUs per frame (bit offsets are
+ * 32-bit; 8K frames fit), else IMGXF_ERR_SHAPE / IMGXF_ERR_ARG. */
 int imgxf_jpeg_workspace_bytes(int n, int h, int w, size_t out_frame_stride, size_t* bytes);
 int imgxf_jpeg_encode_u8(const imgxf_view* src, const imgxf_jpeg_tables* tables, const uint8_t* header,
                          int header_bytes, uint8_t* out, size_t out_frame_stride, uint32_t* sizes,
