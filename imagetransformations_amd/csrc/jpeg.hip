@@ -36,12 +36,25 @@ struct JpegHeader {
     int len;
 };
 
-__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+// jfdctint.c, one 1-D pass over eight values (FIRST: the row pass, results scaled up by 4).  Same sums as the library's
+// (32-bit two's complement, any association); the rounding constant of DESCALE rides in the shared terms z1 / z5 so
+// that every output is one multiply-add chain and a shift.
+// (the multiplies as explicit 24-bit instructions: left to the compiler, the second pass — whose operand ranges it cannot
+// bound — comes out as quarter-rate v_mul_lo_u32 / v_mad_u64_u32)
+__device__ __forceinline__ int mul24c(int a, int c) {
+    int r;
+    asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "s"(c), "v"(a));
+    return r;
+}
+__device__ __forceinline__ int mad24c(int a, int c, int acc) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(c), "v"(acc));
+    return r;
+}
 
-// jfdctint.c, one 1-D pass over eight values (FIRST: the row pass, results scaled up by 4).
 template <bool FIRST>
 __device__ __forceinline__ void fdct8(int& d0, int& d1, int& d2, int& d3, int& d4, int& d5, int& d6, int& d7) {
-    constexpr int N = FIRST ? 11 : 15;
+    constexpr int N = FIRST ? 11 : 15, R = 1 << (N - 1);
     const int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
     const int t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
     const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
@@ -49,27 +62,29 @@ __device__ __forceinline__ void fdct8(int& d0, int& d1, int& d2, int& d3, int& d
         d0 = (t10 + t11) << 2;
         d4 = (t10 - t11) << 2;
     } else {
-        d0 = descale(t10 + t11, 2);
-        d4 = descale(t10 - t11, 2);
+        d0 = (t10 + t11 + 2) >> 2;
+        d4 = (t10 - t11 + 2) >> 2;
     }
-    int z1 = __mul24(t12 + t13, 4433);
-    d2 = descale(z1 + __mul24(t13, 6270), N);
-    d6 = descale(z1 - __mul24(t12, 15137), N);
-    z1 = t4 + t7;
-    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
-    const int z5 = __mul24(z3 + z4, 9633);
-    const int a4 = __mul24(t4, 2446), a5 = __mul24(t5, 16819), a6 = __mul24(t6, 25172), a7 = __mul24(t7, 12299);
-    z1 = -__mul24(z1, 7373);
-    z2 = -__mul24(z2, 20995);
-    z3 = z5 - __mul24(z3, 16069);
-    z4 = z5 - __mul24(z4, 3196);
-    d7 = descale(a4 + z1 + z3, N);
-    d5 = descale(a5 + z2 + z4, N);
-    d3 = descale(a6 + z2 + z3, N);
-    d1 = descale(a7 + z1 + z4, N);
+    const int z1r = mad24c(t12 + t13, 4433, R);
+    d2 = mad24c(t13, 6270, z1r) >> N;
+    d6 = mad24c(t12, -15137, z1r) >> N;
+    const int s1 = t4 + t7, s2 = t5 + t6, s3 = t4 + t6, s4 = t5 + t7;
+    const int z5r = mad24c(s3 + s4, 9633, R);
+    const int z3 = mad24c(s3, -16069, z5r), z4 = mad24c(s4, -3196, z5r);
+    const int z1 = mul24c(s1, -7373), z2 = mul24c(s2, -20995);
+    d7 = mad24c(t4, 2446, z1 + z3) >> N;
+    d5 = mad24c(t5, 16819, z2 + z4) >> N;
+    d3 = mad24c(t6, 25172, z2 + z3) >> N;
+    d1 = mad24c(t7, 12299, z1 + z4) >> N;
 }
 
-__device__ __forceinline__ u32 ycc_y(u32 r, u32 g, u32 b) { return (19595u * r + 38470u * g + 7471u * b + 32768u) >> 16; }
+// jccolor.c: Y = (19595 R + 38470 G + 7471 B + 32768) >> 16 on a dword holding R, G, B in its low three bytes: the 16-bit
+// constants split into bytes for two v_dot4_u32_u8 (76·256+139, 150·256+70, 29·256+47); the fourth byte has weight 0.
+__device__ __forceinline__ u32 ycc_y_dot(u32 rgbx) {
+    const u32 hi = __builtin_amdgcn_udot4(rgbx, 76u | (150u << 8) | (29u << 16), 0u, false);
+    const u32 lo = __builtin_amdgcn_udot4(rgbx, 139u | (70u << 8) | (47u << 16), 32768u, false);
+    return ((hi << 8) + lo) >> 16;
+}
 __device__ __forceinline__ u32 ycc_cb(int r, int g, int b) { return (u32)(-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16; }
 __device__ __forceinline__ u32 ycc_cr(int r, int g, int b) { return (u32)(32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16; }
 
@@ -116,10 +131,10 @@ __global__ __launch_bounds__(JT) void jpeg_transform_kernel(View s, int16_t* __r
         const int r = i / G4, g4 = i - r * G4;
         const u32* p = (const u32*)&rgb[r][g4 * 12];
         const u32 a = p[0], b = p[1], c = p[2];
-        const u32 y0v = ycc_y(a & 255, (a >> 8) & 255, (a >> 16) & 255);
-        const u32 y1v = ycc_y(a >> 24, b & 255, (b >> 8) & 255);
-        const u32 y2v = ycc_y((b >> 16) & 255, b >> 24, c & 255);
-        const u32 y3v = ycc_y((c >> 8) & 255, (c >> 16) & 255, c >> 24);
+        const u32 y0v = ycc_y_dot(a);
+        const u32 y1v = ycc_y_dot(__builtin_amdgcn_alignbit(b, a, 24));
+        const u32 y2v = ycc_y_dot(__builtin_amdgcn_alignbit(c, b, 16));
+        const u32 y3v = ycc_y_dot(c >> 8);
         *(u32*)&yp[r][g4 * 4] = y0v | (y1v << 8) | (y2v << 16) | (y3v << 24);
     }
     // chrominance: two samples (4×2 pixels) per task; rows past the image repeat the last DOWNSAMPLED row
