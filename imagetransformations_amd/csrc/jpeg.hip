@@ -21,6 +21,7 @@ constexpr int JM = 16;                       // MCUs per transform workgroup: 4Â
 constexpr int JT = 128;                      // threads (>= 6Â·JM blocks; 32 MCUs Ã— 192 threads measured slower: 460 vs 430 Âµs)
 constexpr int JPX = 16 * JM;                 // pixels per row of the workgroup's strip
 constexpr int JCHUNK = 32;                   // bytes per stuffing thread
+constexpr unsigned JLW = 4096;               // words of an emit workgroup's span merged in LDS (16 KB)
 
 struct JpegQuant {                           // per coefficient (natural order): |c| â†’ (((|c| + half) << sh) Â· m) >> 32, 24-bit operands
     u32 m[2][64];                            // ceil(2^32 / (8q << sh)) < 2^24, sh = the shift that brings 8q above 256
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void jpeg_lens_kernel(const int16_t* __restric
 __global__ __launch_bounds__(256) void jpeg_emit_kernel(const int16_t* __restrict__ coef, int64_t coef_fs, const int16_t* __restrict__ dcs,
                                                         const u32* __restrict__ offs, u32* __restrict__ stream, int64_t stream_fs_words,
                                                         const u32* __restrict__ total_bits, JpegGeom g, JpegHuff hf) {
-    constexpr u32 LW = 4096;                                  // words of the workgroup's span merged in LDS (16 KB)
+    constexpr u32 LW = JLW;
     __shared__ u32 sdc[2][16];
     __shared__ u32 sac[2][256];
     __shared__ u32 lbuf[LW];
@@ -490,14 +491,24 @@ static int scan_rows(u32* data, int64_t fs, int len, int n, u32* part, u32* tota
 
 // ---- byte stuffing and the file around the entropy-coded segment ----------------------------------------------------
 
-__global__ __launch_bounds__(256) void jpeg_zero_kernel(u32* __restrict__ stream, int64_t fs_words, const u32* __restrict__ total_bits) {
-    const int f = blockIdx.y;
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    const int64_t need = min((int64_t)(((unsigned long long)total_bits[f] + 31) / 32 + 1), fs_words);
-    if (i >= need) return;
-    u32* p = stream + (int64_t)f * fs_words + i;
-    if (i + 4 <= fs_words) *(uint4*)p = make_uint4(0, 0, 0, 0);
-    else for (int e = 0; i + e < fs_words; ++e) p[e] = 0;
+// Before the emit kernel: the words it ORs into must start at zero.  A workgroup whose span is merged in LDS touches
+// only its first and last word that way (everything between is stored whole); a span too long for LDS is cleared entirely.
+__global__ __launch_bounds__(256) void jpeg_zero_kernel(u32* __restrict__ stream, int64_t fs_words, const u32* __restrict__ offs,
+                                                        const u32* __restrict__ total_bits, int nblk) {
+    const int f = blockIdx.y, j0 = blockIdx.x * 256;
+    const u32 tb = total_bits[f];
+    if (((unsigned long long)tb + 31) / 32 > (unsigned long long)fs_words) return;
+    const int j1 = min(j0 + 256, nblk);
+    const u32 sbit = offs[(int64_t)f * nblk + j0];
+    const u32 ebit = j1 < nblk ? offs[(int64_t)f * nblk + j1] : tb;
+    const u32 wlo = sbit >> 5, nw = ((ebit + 31) >> 5) - wlo;
+    u32* gs = stream + (int64_t)f * fs_words + wlo;
+    if (nw <= JLW) {
+        if (threadIdx.x == 0) gs[0] = 0;
+        if (threadIdx.x == 1) gs[nw - 1] = 0;
+    } else {
+        for (u32 i = threadIdx.x; i < nw; i += 256) gs[i] = 0;
+    }
 }
 
 // The eight MSB-first words of chunk ci of a frame's unstuffed stream, bytes past the end cleared and the last byte
@@ -739,8 +750,7 @@ IMGXF_API int imgxf_jpeg_encode_u8(const imgxf_view* src, const imgxf_jpeg_table
     const dim3 bgrid((unsigned)((L.nblk + 255) / 256), (unsigned)s.n);
     hipLaunchKernelGGL(jpeg_lens_kernel, bgrid, dim3(256), 0, st, (const int16_t*)dcs, (const uint16_t*)acb, lens, g, hf);
     IMGXF_CHECK(scan_rows(lens, L.nblk, L.nblk, s.n, part, tot_bits, st));
-    hipLaunchKernelGGL(jpeg_zero_kernel, dim3((unsigned)((L.stream_words / 4 + 255) / 256), (unsigned)s.n), dim3(256), 0, st, ustream,
-                       L.stream_words, (const u32*)tot_bits);
+    hipLaunchKernelGGL(jpeg_zero_kernel, bgrid, dim3(256), 0, st, ustream, L.stream_words, (const u32*)lens, (const u32*)tot_bits, L.nblk);
     hipLaunchKernelGGL(jpeg_emit_kernel, bgrid, dim3(256), 0, st, (const int16_t*)coef, coef_fs, (const int16_t*)dcs, (const u32*)lens,
                        ustream, L.stream_words, (const u32*)tot_bits, g, hf);
     const unsigned cwg = (unsigned)((L.nchunks + 255) / 256);
