@@ -4,12 +4,14 @@
 //
 //   jpeg_transform_kernel   RGB → YCbCr (16-bit fixed point) → 2×2 chroma averaging → 8×8 forward DCT → quantise;
 //                           16 MCUs (16×256 px) per workgroup staged through LDS, one thread per 8×8 block, zigzag
-//                           int16 coefficients in MCU order (6 blocks per MCU) to the workspace
-//                           plus, per block, its DC value and the bits its AC symbols will take
+//                           int16 coefficients in MCU order (6 blocks per MCU), 16-byte pieces interleaved over groups
+//                           of 64 blocks, plus, per block, its DC value and the bits its AC symbols will take
 //   jpeg_lens_kernel        bits per block (DC difference code + AC bits)               → exclusive scan = bit offsets
-//   jpeg_emit_kernel        256 blocks per workgroup through LDS, codes written at the block's bit offset
-//   jpeg_ffcount / jpeg_stuff_kernel   0xFF → 0xFF 0x00 byte stuffing (count per 32-byte chunk, scan, scatter),
-//                           header, padding of the last byte with 1-bits, EOI, file size per frame
+//   jpeg_zero_kernel        clears the stream words the emit kernel ORs into
+//   jpeg_emit_kernel        one thread per block walks its coefficients; a workgroup's 256 blocks form one contiguous
+//                           span of the stream, merged in LDS and stored whole (atomics only on the two shared words)
+//   jpeg_ffcount / jpeg_stuff_kernel   0xFF → 0xFF 0x00 byte stuffing (count per 32-byte chunk on words, scan, expand
+//                           in LDS, coalesced stores), header, padding of the last byte with 1-bits, EOI, file size
 //
 // Integer arithmetic throughout: bit-identical to the library (tests/test_gpu_jpeg.py compares whole files).
 #include "imgxf_common.h"
