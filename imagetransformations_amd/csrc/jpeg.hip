@@ -28,7 +28,7 @@ constexpr unsigned JLW = 4096;               // words of an emit workgroup's spa
 struct JpegQuant {                           // per coefficient (natural order): |c| → (((|c| + half) << sh) · m) >> 32, 24-bit operands
     u32 m[2][64];                            // ceil(2^32 / (8q << sh)) < 2^24, sh = the shift that brings 8q above 256
     u32 half[2][64];                         // 4q | sh << 16
-    u8 aclen[2][256];                        // Huffman code length of the AC symbol (run << 4) | size
+    u8 aclen[2][256];                        // bits of the AC symbol (run << 4) | size: Huffman code length + size
 };
 struct JpegHuff {                            // code | len << 16
     u32 dc[2][16];
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(JT) void jpeg_transform_kernel(View s, int16_t* __r
             const int c = d[zz(i)], sg = c >> 31;
             const u32 a = (u32)((c ^ sg) - sg);
             const u32 cat = 32 - (u32)__clz((int)a);          // 0 for a == 0
-            const u32 add = lt[((run & 15) << 4) | (cat & 15)] + cat;
+            const u32 add = lt[((run & 15) << 4) | cat];       // code length + size; cat <= 11 for 8-bit samples
             bits += a ? add : 0u;
             nzrl += a ? run >> 4 : 0u;                          // ZRL symbols (runs of 16 zeros) before this coefficient
             run = a ? 0u : run + 1;
@@ -726,7 +726,7 @@ IMGXF_API int imgxf_jpeg_encode_u8(const imgxf_view* src, const imgxf_jpeg_table
         for (int i = 0; i < 16; ++i) hf.dc[t][i] = (u32)tables->dc_code[t][i] | ((u32)tables->dc_len[t][i] << 16);
         for (int i = 0; i < 256; ++i) {
             hf.ac[t][i] = (u32)tables->ac_code[t][i] | ((u32)tables->ac_len[t][i] << 16);
-            q.aclen[t][i] = tables->ac_len[t][i];
+            q.aclen[t][i] = (u8)(tables->ac_len[t][i] + (i & 15));      // code + magnitude bits of the symbol
         }
     }
     JpegHeader hd;
