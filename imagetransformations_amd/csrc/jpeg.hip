@@ -215,19 +215,18 @@ __global__ __launch_bounds__(JT) void jpeg_transform_kernel(View s, int16_t* __r
     const int64_t blk = ((int64_t)my * mw + mx0 + ml) * 6 + k;
     {   // bits of the AC part of this block (jchuff.c encode_one_block), so that only the DC term needs the neighbours
         const u8* lt = slen[chroma];
-        u32 bits = 0, run = 0, nzrl = 0;
+        u32 acc = 0, run16 = 0;                                 // acc: bits | ZRL symbols << 16; run16: 16 · zero run
 #pragma unroll
         for (int i = 1; i < 64; ++i) {
-            const int c = d[zz(i)], sg = c >> 31;
-            const u32 a = (u32)((c ^ sg) - sg);
-            const u32 cat = 32 - (u32)__clz((int)a);          // 0 for a == 0
-            const u32 add = lt[((run & 15) << 4) | cat];       // code length + size; cat <= 11 for 8-bit samples
-            bits += a ? add : 0u;
-            nzrl += a ? run >> 4 : 0u;                          // ZRL symbols (runs of 16 zeros) before this coefficient
-            run = a ? 0u : run + 1;
+            const int c = d[zz(i)];
+            const u32 a = (u32)max(c, -c);
+            const u32 cat = 32 - (u32)__clz((int)a);          // 0 for a == 0; <= 11 for 8-bit samples
+            const u32 add = lt[(run16 & 0xf0) | cat] + ((run16 & 0xff00) << 8);   // code length + size; runs of 16 zeros
+            acc += a ? add : 0u;
+            run16 = a ? 0u : run16 + 16;
         }
-        bits += nzrl * lt[0xF0];
-        if (run) bits += lt[0];
+        u32 bits = (acc & 0xffff) + (acc >> 16) * lt[0xF0];
+        if (run16) bits += lt[0];
         acbits[(int64_t)f * nblk + blk] = (uint16_t)bits;
         dcs[(int64_t)f * nblk + blk] = (int16_t)d[0];
     }
