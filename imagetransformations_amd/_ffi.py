@@ -43,6 +43,8 @@ _I32 = C.POINTER(C.c_int32)
 SIGNATURES = {
     "imgxf_version": [],
     "imgxf_device_count": [],
+    "imgxf_reload_knobs": [],
+    "imgxf_probe_sclk": [C.c_void_p, C.c_uint, C.c_void_p],
     "imgxf_gaussian_u8": [_VP, _VP, C.c_int, C.c_double, _VP, C.c_void_p],
     "imgxf_sepconv_u8": [_VP, _VP, _F, C.c_int, _F, C.c_int, C.c_int, _VP, C.c_void_p],
     "imgxf_gaussian_cv_fixed_u8": [_VP, _VP, C.c_int, C.c_double, C.c_void_p],
@@ -142,6 +144,11 @@ def check(code: int, where: str) -> None:
 
 def call(name: str, *args) -> None:
     check(getattr(lib, name)(*args), name)
+
+
+def reload_knobs() -> None:
+    """Re-read the IMGXF_* environment knobs (the library caches them at first use)."""
+    call("imgxf_reload_knobs")
 
 
 def view_of(t, elem_size: int | None = None) -> View:

@@ -1310,23 +1310,22 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
     // batches: every tile loops over `fpb` frames per workgroup with the per-pixel geometry held in
     // registers (affine_mf.inc); single frames and the fp32 side output keep the per-frame kernels
     const bool want_f32 = dbg.p != nullptr;
-    const char* fpb_env = getenv("IMGXF_AFFINE_FPB");
-    const int fpb = fpb_env ? atoi(fpb_env) : 16;
+    const int fpb = knob_int(K_AFFINE_FPB, 16);
     const int afpb = fpb;
     const bool mf = BHT == MF_TILE_H && !want_f32 && afpb >= 2 && d.n >= 2 && bht <= 64 &&
                     (int64_t)d.h * d.rs < ((int64_t)1 << 32);
     // LDS-DMA staging of packed rows needs 16-byte aligned source rows and a box of <= 52 x 52 pixels; it
     // also takes the border tiles (no list pass)
     const int nch = (bwt * 3 + 15 + 15) / 16;                  // 16-byte chunks per packed box row (any alignment of its start)
-    const bool dma = mf && getenv("IMGXF_AFFINE_NO_DMA") == nullptr && bht <= 52 && bwt <= 52 && 52 * nch <= 768 &&
+    const bool dma = mf && !knob_set(K_AFFINE_NO_DMA) && bht <= 52 && bwt <= 52 && 52 * nch <= 768 &&
                      ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 15) == 0 && s.w * 3 >= 16 &&
                      (int64_t)s.h * s.rs < ((int64_t)1 << 32);
     if (dma) {
         dim3 grid((unsigned)(ntx * ntyt), (unsigned)((d.n + afpb - 1) / afpb));
         // RGBX pitch 56: fewest bank conflicts of the multiples of 4 (simulated for 30 deg / 1.5x: 4.0 vs 5.8 LDS cycles per gather read at 52)
-        const int npk = getenv("IMGXF_AFFINE_PK3") ? 3 : 2;        // packed-row buffers (A/B knob)
+        const int npk = knob_set(K_AFFINE_PK3) ? 3 : 2;        // packed-row buffers (A/B knob)
         AffineParams Ps = Pin;
-        if (ntx >= 16 && !getenv("IMGXF_AFFINE_NO_STRIPS")) { Ps.strip_w = (ntx + 7) / 8; grid.x = (unsigned)(8 * Ps.strip_w * ntyt); }
+        if (ntx >= 16 && !knob_set(K_AFFINE_NO_STRIPS)) { Ps.strip_w = (ntx + 7) / 8; grid.x = (unsigned)(8 * Ps.strip_w * ntyt); }
         const size_t lds = (size_t)52 * 56 * 4 + npk * ((size_t)52 * nch * 16 + 64);
         if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, 56, 13, true>), grid, dim3(256), lds, st, s, d, Ps, ntx, ntyt, fpb, nch, npk);
         else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, 56, 13, true>), grid, dim3(256), lds, st, s, d, Ps, ntx, ntyt, fpb, nch, npk);
@@ -1409,7 +1408,7 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
     const View s = make_view(src), d = make_view(dst);
     hipStream_t st = (hipStream_t)stream;
     const bool pr = precise != 0 || filter == IMGXF_FILTER_NEAREST;
-    if (filter == IMGXF_FILTER_NEAREST && src->c == 3 && getenv("IMGXF_AFFINE_NO_LDS") == nullptr &&
+    if (filter == IMGXF_FILTER_NEAREST && src->c == 3 && !knob_set(K_AFFINE_NO_LDS) &&
         ((((uintptr_t)src->data) | (uintptr_t)src->row_stride | (uintptr_t)src->frame_stride) & 3) == 0) {
         // 16.16 coordinates must not wrap 32 bits anywhere in the (tile-padded) output rectangle
         bool nowrap = true;
@@ -1426,18 +1425,18 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
         if (nowrap && bw <= 97 && bh <= 100 && (int64_t)ntx * nty < 0x7fffffff && d.n <= 65535) {
             dim3 grid((unsigned)(ntx * nty), (unsigned)d.n);
             P.ntx_magic = (u32)((((uint64_t)1 << 32) + ntx - 1) / ntx);   // ntx, nty <= 1024: exact; 0 when ntx == 1
-            static const bool no_dma = getenv("IMGXF_AFFINE_NO_DMA") != nullptr;
+            const bool no_dma = knob_set(K_AFFINE_NO_DMA);
             if (bw <= 49 && bh <= 52 && !no_dma && src->w * 3 >= 16 && (src->w * 3) % 16 == 0 &&
                 ((((uintptr_t)src->data) | (uintptr_t)src->row_stride | (uintptr_t)src->frame_stride) & 15) == 0) {
                 // 32x64 tiles when their source box fits 13 chunks x 80 rows, else 32x32
                 const int bw64 = (int)ceil((fabs((double)P.fx[0]) * 31 + fabs((double)P.fx[1]) * 63) / 65536.0) + 3;
                 const int bh64 = (int)ceil((fabs((double)P.fx[3]) * 31 + fabs((double)P.fx[4]) * 63) / 65536.0) + 3;
-                static const bool no_tall = getenv("IMGXF_AFFINE_NO_TALL") != nullptr;
+                const bool no_tall = knob_set(K_AFFINE_NO_TALL);
                 if (bw64 <= 64 && bh64 <= 80 && !no_tall) {
                     const int nty64 = (d.h + 63) / 64;
                     unsigned gx = (unsigned)(ntx * nty64);
                     // vertical strips per XCD (3 % at 4K: 0.86 -> 0.83 ms per 64 frames); IMGXF_AFFINE_NO_STRIPS = row-major ranges
-                    if (ntx >= 16 && !getenv("IMGXF_AFFINE_NO_STRIPS")) { P.strip_w = (ntx + 7) / 8; gx = (unsigned)(8 * P.strip_w * nty64); }
+                    if (ntx >= 16 && !knob_set(K_AFFINE_NO_STRIPS)) { P.strip_w = (ntx + 7) / 8; gx = (unsigned)(8 * P.strip_w * nty64); }
                     hipLaunchKernelGGL((affine_nearest_dma_kernel<64, 13>), dim3(gx, (unsigned)d.n), dim3(256),
                                        (size_t)13 * 16 * bh64 + 32, st, s, d, P, ntx, nty64);
                 } else {
@@ -1474,8 +1473,8 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
         P.y00 = (int64_t)floor(y0d * 1099511627776.0);
     }
     if (filter == IMGXF_FILTER_BILINEAR && (src->c == 1 || src->c == 3) && src->w >= 3 && src->h >= 2 && fixed_ok) {
-        static const int tile_env = getenv("IMGXF_AFFINE_TILE") ? atoi(getenv("IMGXF_AFFINE_TILE")) : 0;  // tuning knob
-        static const bool no_lds = getenv("IMGXF_AFFINE_NO_LDS") != nullptr;
+        const int tile_env = knob_int(K_AFFINE_TILE, 0);  // tuning knob
+        const bool no_lds = knob_set(K_AFFINE_NO_LDS);
         if (src->c == 3 && !no_lds && tile_env == 0 &&
             ((((uintptr_t)src->data) | (uintptr_t)src->row_stride | (uintptr_t)src->frame_stride) & 3) == 0) {
             // source bounding box of a 32x32 output tile (translation-invariant up to rounding)
@@ -1503,7 +1502,7 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
     } while (0)
                 // interior tiles as 32x64 (8 pixels per lane) + a host-built list of the others, when
                 // the geometry qualifies
-                static const bool no_tall = getenv("IMGXF_AFFINE_NO_TALL") != nullptr;
+                const bool no_tall = knob_set(K_AFFINE_NO_TALL);
                 if (!no_tall) {
                     const int rc = launch_bilinear_tall<64, 49, 64>(s, d, P, dbg, m, bw, bh, ntx, pr, st);
                     if (rc != BILINEAR_TALL_NOT_TAKEN) return rc;     // (32x128 tiles measured slower: 1.18 vs 1.08 ms)
@@ -1534,7 +1533,7 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
 #undef IMGXF_BIL
     }
     {
-        static const bool no_shear = getenv("IMGXF_AFFINE_NO_SHEAR_FAST") != nullptr;
+        const bool no_shear = knob_set(K_AFFINE_NO_SHEAR_FAST);
         const bool honly = m[3] == 0.0 && m[4] == 1.0 && m[5] == floor(m[5]) && fabs(m[5]) < 1.0e9;
         if (filter == IMGXF_FILTER_BICUBIC && honly && src->c == 3 && !dbg.p && !no_shear && src->w >= 4) {
             dim3 block(256), grid((unsigned)((d.w + 1023) / 1024), (unsigned)d.h, (unsigned)d.n);

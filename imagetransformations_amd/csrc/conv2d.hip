@@ -392,7 +392,7 @@ IMGXF_API int imgxf_box_blur_u8(const imgxf_view* src, const imgxf_view* dst, fl
             const View out = to_dst ? d : ws;
             // wide-lane kernels for 16-byte aligned images and the radii GaussianBlur produces (radius <= 4)
             const bool al16 = ((((uintptr_t)cur.p) | (uintptr_t)cur.rs | (uintptr_t)cur.fs | ((uintptr_t)out.p) | (uintptr_t)out.rs | (uintptr_t)out.fs) & 15) == 0 &&
-                              s.rowbytes() % 16 == 0 && s.rowbytes() >= 48 && !getenv("IMGXF_BOX_BYTES");
+                              s.rowbytes() % 16 == 0 && s.rowbytes() >= 48 && !knob_set(K_BOX_BYTES);
             const unsigned b16 = (unsigned)std::min<int64_t>(32768, ((int64_t)s.n * s.h * (s.rowbytes() >> 4) + 255) / 256);
             bool launched = false;
             if (al16 && radius <= BOX_RMAX) {
@@ -430,7 +430,7 @@ IMGXF_API int imgxf_filter3x3_u8(const imgxf_view* src, const imgxf_view* dst, c
     K.off = offset + 0.5f;
     const View s = make_view(src), d = make_view(dst);
     if (((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | ((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs) & 15) == 0 &&
-        s.rowbytes() >= 48 && !getenv("IMGXF_FILTER3X3_BYTES")) {
+        s.rowbytes() >= 48 && !knob_set(K_FILTER3X3_BYTES)) {
         const int64_t total16 = (int64_t)s.n * s.h * ((s.rowbytes() + 15) >> 4);
         int64_t blocks16 = (total16 + 255) / 256;
         if (blocks16 > 32768) blocks16 = 32768;
@@ -463,7 +463,7 @@ IMGXF_API int imgxf_conv2d_u8(const imgxf_view* src, const imgxf_view* dst, cons
     // separable kernels (marching / matrix-core Gaussians: 0.6 - 1.1 ms per 64 4K frames instead of 4 - 14 ms
     // here); the factorisation reproduces K to 1e-6 of its largest entry, inside the 1e-5 contract of this
     // float filter, and both evaluate sum(w p) in fp32 with one rounding to uint8.
-    if (!getenv("IMGXF_CONV2D_NO_SEPARABLE")) {
+    if (!knob_set(K_CONV2D_NO_SEPARABLE)) {
         int pj = 0, pi = 0;
         double pmax = 0.0;
         for (int j = 0; j < kh; ++j)
@@ -498,7 +498,7 @@ IMGXF_API int imgxf_sobel_u8(const imgxf_view* src, const imgxf_view* dst, int v
     if (variant < 0 || variant > 2) return IMGXF_ERR_ARG;
     if (empty_view(src)) return IMGXF_OK;
     const View s = make_view(src), d = make_view(dst);
-    static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
+    const bool no_march = knob_set(K_NO_MARCH);
     if (!no_march && sobel_march_eligible(s, d, 1)) {
         switch (variant) {
             case IMGXF_SOBEL_X_WRAP: return launch_sobel_march<1, IMGXF_SOBEL_X_WRAP>(s, d, (hipStream_t)stream);
@@ -518,7 +518,7 @@ IMGXF_API int imgxf_rgb_sobel_u8(const imgxf_view* src, const imgxf_view* dst, i
     if (variant < 0 || variant > 2) return IMGXF_ERR_ARG;
     if (empty_view(src)) return IMGXF_OK;
     const View s = make_view(src), d = make_view(dst);
-    static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
+    const bool no_march = knob_set(K_NO_MARCH);
     if (!no_march && sobel_march_eligible(s, d, 3)) {
         switch (variant) {
             case IMGXF_SOBEL_X_WRAP: return launch_sobel_march<3, IMGXF_SOBEL_X_WRAP>(s, d, (hipStream_t)stream);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "imgxf.h"
+#include "knobs.h"
 
 #define IMGXF_API extern "C" __attribute__((visibility("default")))
 

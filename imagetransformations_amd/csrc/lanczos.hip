@@ -468,7 +468,7 @@ static inline unsigned grid_for(int64_t total) {
 static int launch_h_fast(const imgxf_lanczos_plan* p, const View& s, const View& d, hipStream_t st) {
     const int rpb = 32;
     dim3 grid((unsigned)((d.w + 1023) / 1024), (unsigned)((d.h + rpb - 1) / rpb), (unsigned)d.n);
-    static const bool no_lds = getenv("IMGXF_LANCZOS_NO_LDS") != nullptr;
+    const bool no_lds = knob_set(K_LANCZOS_NO_LDS);
     const bool aligned = ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 15) == 0 && (s.w * 3) % 16 == 0;
     if (!no_lds && aligned && p->hspan > 0 && p->hspan <= 8192) {
         const int bufbytes = (p->hspan + 15) & ~15;
@@ -494,7 +494,7 @@ static bool v_fast_ok(const imgxf_lanczos_plan* p, const View& s, const View& d)
 }
 
 static int launch_v_fast(const imgxf_lanczos_plan* p, const View& s, const View& d, hipStream_t st) {
-    static const bool no_v4 = getenv("IMGXF_LANCZOS_NO_V4") != nullptr;
+    static const bool no_v4 = knob_set(K_LANCZOS_NO_V4);
     if (p->ku4 == 12 && !no_v4) {
         dim3 grid4((unsigned)(((d.rowbytes() >> 4) + 255) / 256), (unsigned)((d.h + 3) / 4), (unsigned)d.n);
         hipLaunchKernelGGL((resample_v4_kernel<12>), grid4, dim3(256), 0, st, s, d, p->d_start4_y, p->d_pk4_y);
@@ -509,6 +509,11 @@ static int launch_v_fast(const imgxf_lanczos_plan* p, const View& s, const View&
 static bool rs_mf_ok(const imgxf_lanczos_plan* p, const View& s, const View& d) {
     if (!p->mf_nkh) return false;
     if (((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | ((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs) & 3) != 0) return false;
+    // the workgroup count of the launch (the widest setting of IMGXF_RESAMPLE_MFMA_WAVES gives the most) must fit
+    // the grid: decided HERE so that the workspace query and the run agree and an oversized call takes the
+    // two-pass path with its intermediate
+    const int64_t total = (int64_t)((p->mf_ng + 3) / 4) * p->mf_nchunks * s.n;
+    if (total > (int64_t(1) << 30)) return false;
     return s.rs > 0 && s.rs < (1 << 24) && p->rh < (1 << 24) && (int64_t)(p->ry0 + p->rh) * s.rs < (int64_t(1) << 31);
 }
 
@@ -524,8 +529,8 @@ static void launch_rs_mf_t(int nkh, dim3 grid, hipStream_t st, const View& s, co
 }
 
 static int launch_rs_mf(const imgxf_lanczos_plan* p, const View& s, const View& d, hipStream_t st) {
-    const char* e = getenv("IMGXF_RESAMPLE_MFMA_WAVES");         // waves per workgroup, 4 or 8 (A/B knob; a wash at 4K)
-    const int nw = e && atoi(e) == 8 ? 8 : 4;
+    const int nw_env = knob_int(K_RESAMPLE_MFMA_WAVES, 4);         // waves per workgroup, 4 or 8 (A/B knob; a wash at 4K)
+    const int nw = nw_env == 8 ? 8 : 4;
     RsMfArgs a;
     a.ws = p->d_mf_ws; a.wh = (const rs_v4i*)p->d_mf_wh; a.kcol = p->d_mf_kcol; a.sched = p->d_mf_sched;
     a.chunks = p->d_mf_chunks; a.wv = (const u8*)p->d_mf_wv; a.krow = p->d_mf_krow;
@@ -684,8 +689,7 @@ IMGXF_API int imgxf_resample_plan_create_window(imgxf_lanczos_plan** plan, int i
         }
     }
     if (rc == IMGXF_OK && p->need_h && p->need_v) {
-        const char* e = getenv("IMGXF_RESAMPLE_MFMA_OC");
-        const int oc = e ? atoi(e) : 16;
+        const int oc = knob_int(K_RESAMPLE_MFMA_OC, 16);
         RsMfTables t;
         if (oc > 0 && oc <= RSMF_MAX_OC && build_rs_mf_tables(bxv, kxv, p->ksx, by, ky, p->ksy, in_w, c, in_h, out_w, out_h, oc, t)) {
             if ((rc = upload(t.ws, &p->d_mf_ws)) == IMGXF_OK && (rc = upload(t.kcol, &p->d_mf_kcol)) == IMGXF_OK &&
@@ -761,7 +765,7 @@ IMGXF_API int imgxf_resize_lanczos_u8(const imgxf_lanczos_plan* p, const imgxf_v
 static bool resample_runs_fused(const imgxf_lanczos_plan* p, const imgxf_view* src, const imgxf_view* dst) {
     if (!p->need_h || !p->need_v || !src || !dst) return false;
     // the knobs that pick a variant of the two-pass kernels imply the two-pass path
-    if (getenv("IMGXF_LANCZOS_SLOW") || getenv("IMGXF_RESAMPLE_NO_MFMA") || getenv("IMGXF_LANCZOS_NO_LDS") || getenv("IMGXF_LANCZOS_NO_V4"))
+    if (knob_set(K_LANCZOS_SLOW) || knob_set(K_RESAMPLE_NO_MFMA) || knob_set(K_LANCZOS_NO_LDS) || knob_set(K_LANCZOS_NO_V4))
         return false;
     return rs_mf_ok(p, make_view(src), make_view(dst));
 }
@@ -803,7 +807,7 @@ static int run_resample(const imgxf_lanczos_plan* p, const imgxf_view* src, cons
         }
         return IMGXF_OK;
     }
-    static const bool slow = getenv("IMGXF_LANCZOS_SLOW") != nullptr;
+    const bool slow = knob_set(K_LANCZOS_SLOW);
     auto run_h = [&](const View& a, const View& b) {
         if (p->kpx && !slow) return launch_h_fast(p, a, b, st);
         return launch_h(a, b, p->d_bounds_x, p->d_kk_x, p->ksx, st);

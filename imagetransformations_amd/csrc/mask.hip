@@ -274,7 +274,7 @@ IMGXF_API int imgxf_dilate_cross_u8(const imgxf_view* src, const imgxf_view* dst
     if (iterations < 1 || iterations > 16) return IMGXF_ERR_ARG;
     if (empty_view(src)) return IMGXF_OK;
     const View d = make_view(dst), sv = make_view(src);
-    static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
+    const bool no_march = knob_set(K_NO_MARCH);
     if (iterations == 3 && !no_march && d.w % 16 == 0 && d.w >= 64 && d.n <= 65535 &&
         ((((uintptr_t)sv.p) | (uintptr_t)sv.rs | (uintptr_t)sv.fs | (uintptr_t)d.p | (uintptr_t)d.rs | (uintptr_t)d.fs) & 15) == 0) {
         const int nstrips = (d.w + 991) / 992;

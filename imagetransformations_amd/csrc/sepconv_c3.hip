@@ -7,8 +7,8 @@
 namespace imgxf {
 int sepconv_c3(int R, const View& s, const View& d, const View& df, const Taps& taps,
                int border, hipStream_t st) {
-    const int rpw_env = getenv("IMGXF_MARCH_RPW") ? atoi(getenv("IMGXF_MARCH_RPW")) : 0;
-    static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
+    const int rpw_env = knob_int(K_MARCH_RPW, 0);
+    const bool no_march = knob_set(K_NO_MARCH);
     if (!no_march && march_eligible(s, d, df, 3, R, border)) {
         switch (R) {
 #define IMGXF_M(r) case r: return launch_sepconv_march<3, r>(s, d, df, taps, st, rpw_env);
@@ -21,9 +21,8 @@ int sepconv_c3(int R, const View& s, const View& d, const View& df, const Taps& 
     // on the radius (1.08 - 1.14 ms per 64 4K frames at k = 13 ... 21, 1.29 - 1.32 ms at k = 25 ... 31) while the vector
     // kernel grows with it (1.30 / 1.46 / 1.84 / 3.30 ms at k = 13 / 15 / 19 / 31; 0.85 ms at k = 9): R >= 6 goes to the
     // matrix cores (IMGXF_MFMA_MIN_R moves the threshold)
-    const char* mr = getenv("IMGXF_MFMA_MIN_R");
-    const int mfma_min_r = mr ? atoi(mr) : 6;
-    if (!no_march && R >= mfma_min_r && mfma_eligible(s, d, df, 3, R, border)) {
+    const int mfma_min_r = knob_int(K_MFMA_MIN_R, 6);
+    if (!no_march && R >= mfma_min_r && mfma_eligible(s, d, df, 3, R, border, taps)) {
         switch (R) {
 #define IMGXF_MM(r) case r: return launch_sepconv_mfma<r>(s, d, df, taps, st);
             IMGXF_MM(2) IMGXF_MM(3) IMGXF_MM(4) IMGXF_MM(5) IMGXF_MM(6) IMGXF_MM(7) IMGXF_MM(8) IMGXF_MM(9) IMGXF_MM(10) IMGXF_MM(11) IMGXF_MM(12) IMGXF_MM(13) IMGXF_MM(14) IMGXF_MM(15)

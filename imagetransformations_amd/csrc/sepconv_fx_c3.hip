@@ -7,8 +7,8 @@
 namespace imgxf {
 int sepconv_fx_c3(int R, const View& s, const View& d, const View& df, const Taps& taps,
                int border, hipStream_t st) {
-    const int rpw_env = getenv("IMGXF_MARCH_RPW") ? atoi(getenv("IMGXF_MARCH_RPW")) : 0;
-    static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
+    const int rpw_env = knob_int(K_MARCH_RPW, 0);
+    const bool no_march = knob_set(K_NO_MARCH);
     if (!no_march && march_eligible(s, d, df, 3, R, border)) {
         switch (R) {
 #define IMGXF_M(r) case r: return launch_sepconv_march<3, r, true>(s, d, df, taps, st, rpw_env);
@@ -18,8 +18,7 @@ int sepconv_fx_c3(int R, const View& s, const View& d, const View& df, const Tap
         }
     }
     // larger radii: exact integer band products on the i8 matrix cores (sepconv_fx_mfma.inc); IMGXF_FX_MFMA_MIN_R moves the threshold
-    const char* mr = getenv("IMGXF_FX_MFMA_MIN_R");
-    const int fx_min_r = mr ? atoi(mr) : 5;
+    const int fx_min_r = knob_int(K_FX_MFMA_MIN_R, 5);
     if (!no_march && R >= fx_min_r && fx_mfma_eligible(s, d, df, 3, R, border, taps)) {
         switch (R) {
 #define IMGXF_FM(r) case r: return launch_sepconv_fx_mfma<r>(s, d, taps, st);

@@ -6,8 +6,8 @@
 namespace imgxf {
 int sepconv_fx_c4(int R, const View& s, const View& d, const View& df, const Taps& taps,
                int border, hipStream_t st) {
-    const int rpw_env = getenv("IMGXF_MARCH_RPW") ? atoi(getenv("IMGXF_MARCH_RPW")) : 0;
-    static const bool no_march = getenv("IMGXF_NO_MARCH") != nullptr;
+    const int rpw_env = knob_int(K_MARCH_RPW, 0);
+    const bool no_march = knob_set(K_NO_MARCH);
     if (!no_march && march_eligible(s, d, df, 4, R, border)) {
         switch (R) {
 #define IMGXF_M(r) case r: return launch_sepconv_march<4, r, true>(s, d, df, taps, st, rpw_env);

@@ -101,8 +101,9 @@ def encode_device(frames: torch.Tensor, quality: int = 75, capacity: int | None 
     F.call("imgxf_jpeg_workspace_bytes", n, h, w, cap, ctypes.byref(nbytes))
     ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=frames.device)
     view = F.view_of(frames)
-    F.call("imgxf_jpeg_encode_u8", F.vp(view), ctypes.addressof(tables(quality)), hdr, len(hdr), files.data_ptr(), cap,
-           sizes.data_ptr(), ws.data_ptr(), nbytes.value, torch.cuda.current_stream(frames.device).cuda_stream)
+    with torch.cuda.device(frames.device):       # the frames' device, not torch's current one (as ops._launch)
+        F.call("imgxf_jpeg_encode_u8", F.vp(view), ctypes.addressof(tables(quality)), hdr, len(hdr), files.data_ptr(), cap,
+               sizes.data_ptr(), ws.data_ptr(), nbytes.value, torch.cuda.current_stream(frames.device).cuda_stream)
     return files, sizes.to(torch.int64) & 0xFFFFFFFF
 
 

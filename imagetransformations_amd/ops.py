@@ -64,6 +64,19 @@ def _like(t: torch.Tensor, h: int | None = None, w: int | None = None, c: int | 
     return torch.empty(shape, dtype=dtype, device=t.device)
 
 
+def _out(out: torch.Tensor | None, like_shape, device, make) -> torch.Tensor:
+    """The destination of an op: a fresh tensor, or the caller's pre-allocated `out` (checked)."""
+    if out is None:
+        return make()
+    if out.dtype != torch.uint8 or out.device != device or tuple(out.shape) != tuple(like_shape):
+        raise ValueError(f"out must be a uint8 tensor of shape {tuple(like_shape)} on {device}")
+    return out
+
+
+def _like_shape(t: torch.Tensor, h: int, w: int):
+    return (h, w) if t.dim() == 2 else tuple(t.shape[:-3]) + (h, w, t.shape[-1])
+
+
 def _hwc(t: torch.Tensor):
     if t.dim() == 2:
         return t.shape[0], t.shape[1], 1
@@ -72,11 +85,12 @@ def _hwc(t: torch.Tensor):
 
 # ---------------------------------------------------------------- a1 Gaussian / separable
 def gaussian_blur(t: torch.Tensor, ksize: int, sigma: float, return_f32: bool = False,
-                  fixed_point: bool = False):
+                  fixed_point: bool = False, out: torch.Tensor | None = None):
     """cv2.GaussianBlur(img, (ksize, ksize), sigma) — transformation.py:249.  fixed_point=True:
-    OpenCV's 8-bit fixed-point evaluation (restated, unpinned) instead of the float definition."""
+    OpenCV's 8-bit fixed-point evaluation (restated, unpinned) instead of the float definition.
+    `out`: optional pre-allocated destination (same shape; may be a strided view)."""
     t = _check_u8(t)
-    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    out = _out(out, t.shape, t.device, lambda: torch.empty_like(t, memory_format=torch.contiguous_format))
     if fixed_point:
         if return_f32:
             raise ValueError("the fixed-point path has no fp32 intermediate")
@@ -134,10 +148,11 @@ def sobel(gray: torch.Tensor, variant: int = F.SOBEL_X_WRAP) -> torch.Tensor:
     return out
 
 
-def rgb_sobel_magnitude(rgb: torch.Tensor) -> torch.Tensor:
+def rgb_sobel_magnitude(rgb: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     """Fused RGB -> L -> (Gx,Gy) -> |G| -> uint8 (benchmark configs[2])."""
     rgb = _check_u8(rgb)
-    out = _gray_like(rgb)
+    out = _out(out, tuple(rgb.shape[:-1]) + (1,) if rgb.dim() == 4 else tuple(rgb.shape[:2]), rgb.device,
+               lambda: _gray_like(rgb))
     _launch(rgb, "imgxf_rgb_sobel_mag_u8", F.vp(F.view_of(rgb)), F.vp(_gray_view(out)))
     return out
 
@@ -165,7 +180,8 @@ def _gray_like(t: torch.Tensor) -> torch.Tensor:
 
 # ---------------------------------------------------------------- a2 affine family
 def affine(t: torch.Tensor, matrix: Sequence[float], out_size: tuple[int, int] | None = None,
-           resample: int = NEAREST, fillcolor=None, precise: bool = True, return_f32: bool = False):
+           resample: int = NEAREST, fillcolor=None, precise: bool = True, return_f32: bool = False,
+           out: torch.Tensor | None = None):
     """Image.transform(out_size, AFFINE, matrix, resample, fillcolor=fillcolor).
 
     `out_size` is (width, height) like Pillow.  NEAREST with a pure scale/translate
@@ -176,7 +192,7 @@ def affine(t: torch.Tensor, matrix: Sequence[float], out_size: tuple[int, int] |
     m = [float(v) for v in matrix][:6]
     if len(m) != 6:
         raise ValueError("affine matrix needs 6 coefficients")
-    out = _like(t, oh, ow)
+    out = _out(out, _like_shape(t, oh, ow), t.device, lambda: _like(t, oh, ow))
     fill = _fill_bytes(fillcolor, c)
     if resample == NEAREST and m[1] == 0.0 and m[3] == 0.0:
         ws = torch.empty(ow + oh + 2, dtype=torch.int32, device=t.device)
@@ -259,18 +275,15 @@ def rot90(t: torch.Tensor, quarter_turns_ccw: int) -> torch.Tensor:
 
 
 def rotate(t: torch.Tensor, angle: float, resample: int = NEAREST, fillcolor=None,
-           precise: bool = True) -> torch.Tensor:
+           precise: bool = True, out: torch.Tensor | None = None) -> torch.Tensor:
     """Image.rotate(angle, resample, expand=False, fillcolor=fillcolor) incl. its fast paths."""
     t = _check_u8(t)
     h, w, _ = _hwc(t)
     a = angle % 360.0
-    if a == 0:
-        return t.clone()
-    if a == 180:
-        return rot90(t, 2)
-    if a in (90, 270) and w == h:
-        return rot90(t, 1 if a == 90 else 3)
-    return affine(t, rotate_matrix(w, h, angle), (w, h), resample, fillcolor, precise)
+    if a == 0 or a == 180 or (a in (90, 270) and w == h):
+        res = t.clone() if a == 0 else rot90(t, 2 if a == 180 else (1 if a == 90 else 3))
+        return res if out is None else out.copy_(res)
+    return affine(t, rotate_matrix(w, h, angle), (w, h), resample, fillcolor, precise, out=out)
 
 
 # ---------------------------------------------------------------- a3 Lanczos resize
@@ -354,7 +367,7 @@ def resize(t: torch.Tensor, size: tuple[int, int], resample: int = RESAMPLE_BICU
 
 
 def resize_crop(t: torch.Tensor, size: tuple[int, int], box: tuple[int, int, int, int],
-                resample: int = RESAMPLE_LANCZOS) -> torch.Tensor:
+                resample: int = RESAMPLE_LANCZOS, out: torch.Tensor | None = None) -> torch.Tensor:
     """img.resize(size, resample).crop(box) without computing the cropped-away pixels: only the
     window's columns are filtered horizontally (and only the source rows its vertical taps
     touch), only its rows vertically.  Same coefficients, bit-identical to resize + crop."""
@@ -365,9 +378,10 @@ def resize_crop(t: torch.Tensor, size: tuple[int, int], box: tuple[int, int, int
     if not (0 <= l < r <= nw and 0 <= tp < b <= nh):
         raise ValueError("crop box must lie inside the resized image")
     if nw == w or nh == h:
-        return crop(resize(t, size, resample), box)
+        res = crop(resize(t, size, resample), box)
+        return res if out is None else out.copy_(res)
     n = t.shape[0] if t.dim() == 4 else 1
-    out = _like(t, b - tp, r - l)
+    out = _out(out, _like_shape(t, b - tp, r - l), t.device, lambda: _like(t, b - tp, r - l))
     if n == 0:
         return out
     plan = _plans.get(h, w, nh, nw, c, t.device.index or 0, int(resample), (l, tp, r - l, b - tp))

@@ -37,6 +37,11 @@ def _world(group=None) -> tuple[int, int]:
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def _peer(group, r: int) -> int:
+    """P2POp addresses peers by GLOBAL rank; `r` is a rank of `group` (identical without a sub-group)."""
+    return r if group is None else dist.get_global_rank(group, r)
+
+
 def scatter_frames(frames: Optional[torch.Tensor], n_frames: int, frame_shape: Sequence[int],
                    device: torch.device, root: int = 0, group=None) -> torch.Tensor:
     """Root holds `frames` [n_frames, *frame_shape] uint8; every rank returns its block."""
@@ -52,9 +57,9 @@ def scatter_frames(frames: Optional[torch.Tensor], n_frames: int, frame_shape: S
             if peer == root:
                 local.copy_(frames[s:e])
             elif e > s:
-                ops.append(dist.P2POp(dist.isend, frames[s:e].contiguous(), peer, group))
+                ops.append(dist.P2POp(dist.isend, frames[s:e].contiguous(), _peer(group, peer), group))
     elif stop > start:
-        ops.append(dist.P2POp(dist.irecv, local, root, group))
+        ops.append(dist.P2POp(dist.irecv, local, _peer(group, root), group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
@@ -75,9 +80,9 @@ def gather_frames(local: torch.Tensor, n_frames: int, root: int = 0, group=None)
             if peer == root:
                 out[s:e].copy_(local)
             elif e > s:
-                ops.append(dist.P2POp(dist.irecv, out[s:e], peer, group))
+                ops.append(dist.P2POp(dist.irecv, out[s:e], _peer(group, peer), group))
     elif local.shape[0] > 0:
-        ops.append(dist.P2POp(dist.isend, local.contiguous(), root, group))
+        ops.append(dist.P2POp(dist.isend, local.contiguous(), _peer(group, root), group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
@@ -102,7 +107,8 @@ def map_frames(fn: Callable[[torch.Tensor], torch.Tensor], frames: Optional[torc
 
 
 def map_frames_pipelined(fn: Callable[[torch.Tensor], torch.Tensor], frames: Optional[torch.Tensor], n_frames: int,
-                         frame_shape: Sequence[int], device: torch.device, chunk: int = 8, root: int = 0, group=None):
+                         frame_shape: Sequence[int], device: torch.device, chunk: int = 8, root: int = 0, group=None,
+                         out_shape: Optional[Sequence[int]] = None, out_dtype: torch.dtype = torch.uint8):
     """map_frames as a three-stage pipeline over chunks of `chunk` frames:
 
         step s:   transfers { input chunk s  root -> peers,  output chunk s-2  peers -> root }
@@ -112,8 +118,12 @@ def map_frames_pipelined(fn: Callable[[torch.Tensor], torch.Tensor], frames: Opt
     sends and receives of a group concurrently, each root<->peer pair on its own xGMI link), issued
     before the step's compute and waited for after it, so a rank computes chunk s-1 while chunk s
     arrives and the result of chunk s-2 leaves.  `fn` must map [k, *frame_shape] -> [k, *out_shape]
-    frame by frame (any `ops` function).  Returns the gathered result on the root, None elsewhere;
-    equal to map_frames for every chunk size."""
+    frame by frame (any `ops` function).  Returns the gathered result on the root (an empty
+    [0, *out_shape] tensor for an empty batch, like map_frames), None elsewhere; equal to map_frames
+    for every chunk size.  `out_shape` / `out_dtype` (per-frame geometry of fn's result) are only
+    needed when fn changes the geometry AND the root owns no frame (fewer frames than ranks with
+    root != 0); without them that root learns the geometry from rank 0's first result — fn is never
+    run on a frame its rank does not own."""
     rank, world = _world(group)
     if chunk < 1:
         raise ValueError("chunk >= 1 required")
@@ -124,6 +134,11 @@ def map_frames_pipelined(fn: Callable[[torch.Tensor], torch.Tensor], frames: Opt
         mine = stop - start
         counts = shard_counts(n_frames, world)
         nsteps = (max(counts) + chunk - 1) // chunk
+        if n_frames == 0:
+            shape = tuple(out_shape) if out_shape is not None else tuple(frame_shape)
+            return torch.empty((0, *shape), dtype=out_dtype, device=device) if rank == root else None
+        # a root without frames cannot see fn's output geometry: rank 0 (which always owns frames) tells it
+        tell_root = counts[root] == 0 and out_shape is None
 
         def piece(r: int, k: int) -> tuple[int, int]:
             """frames [a, b) of rank r's block that form its chunk k (empty when k is out of range)"""
@@ -145,17 +160,17 @@ def map_frames_pipelined(fn: Callable[[torch.Tensor], torch.Tensor], frames: Opt
                     ps, _ = shard_range(n_frames, world, peer)
                     a, b = piece(peer, s)
                     if b > a:
-                        ops.append(dist.P2POp(dist.isend, frames[ps + a:ps + b].contiguous(), peer, group))
+                        ops.append(dist.P2POp(dist.isend, frames[ps + a:ps + b].contiguous(), _peer(group, peer), group))
                     a, b = piece(peer, s - 2)
                     if s >= 2 and b > a:
-                        ops.append(dist.P2POp(dist.irecv, result[ps + a:ps + b], peer, group))
+                        ops.append(dist.P2POp(dist.irecv, result[ps + a:ps + b], _peer(group, peer), group))
             else:
                 a, b = piece(rank, s)
                 if b > a:
-                    ops.append(dist.P2POp(dist.irecv, local_in[a:b], root, group))
+                    ops.append(dist.P2POp(dist.irecv, local_in[a:b], _peer(group, root), group))
                 a, b = piece(rank, s - 2)
                 if s >= 2 and b > a:
-                    ops.append(dist.P2POp(dist.isend, local_out[a:b], root, group))
+                    ops.append(dist.P2POp(dist.isend, local_out[a:b], _peer(group, root), group))
             reqs = dist.batch_isend_irecv(ops) if ops else []
             # ---- compute chunk s-1 (its input arrived with step s-1's transfers)
             a, b = piece(rank, s - 1)
@@ -169,22 +184,57 @@ def map_frames_pipelined(fn: Callable[[torch.Tensor], torch.Tensor], frames: Opt
                     if local_out is None:
                         local_out = torch.empty((mine, *y.shape[1:]), dtype=y.dtype, device=y.device)
                     local_out[a:b].copy_(y)
-            if is_root and s == 1 and result is None and n_frames > 0:
-                # an empty root block (root != 0, fewer frames than ranks): the output geometry of the
-                # receives posted from step 2 on comes from one probe frame
-                y = fn(frames[:1])
-                result = torch.empty((n_frames, *y.shape[1:]), dtype=y.dtype, device=y.device)
+            if s == 1 and counts[root] == 0:
+                # an empty root block (root != 0, fewer frames than ranks): the geometry of the receives
+                # posted from step 2 on is given by the caller or sent by rank 0 after its first chunk
+                if tell_root and (rank == 0 or is_root):
+                    meta = torch.zeros(10, dtype=torch.int64, device=device)
+                    if rank == 0:
+                        dims = list(local_out.shape[1:])
+                        meta[:2 + len(dims)] = torch.tensor([_DTYPES.index(local_out.dtype), len(dims), *dims])
+                        dist.send(meta, _peer(group, root), group)
+                    else:
+                        dist.recv(meta, _peer(group, 0), group)
+                        m = meta.tolist()
+                        out_dtype, out_shape = _DTYPES[m[0]], tuple(m[2:2 + m[1]])
+                if is_root:
+                    result = torch.empty((n_frames, *out_shape), dtype=out_dtype, device=device)
             for req in reqs:
                 req.wait()
         return result if is_root else None
 
 
+_DTYPES = [torch.uint8, torch.float32, torch.int32, torch.int64, torch.float16, torch.float64, torch.int16, torch.int8]
+
+
 def checksum(t: torch.Tensor, group=None) -> int:
-    """Order-independent checksum of a sharded batch: sum over ranks of sum(bytes * position
-    weight).  Equal for any sharding of the same frames when `offset` numbering is global."""
+    """Byte sum of a sharded batch, summed over the ranks: equal for any sharding of the same frames
+    (and blind to their order — `checksum_weighted` is the one that sees misplaced frames)."""
     rank, world = _world(group)
     v = t.reshape(t.shape[0], -1).to(torch.int64).sum(dim=1) if t.shape[0] else torch.zeros(0, dtype=torch.int64, device=t.device)
     total = v.sum().reshape(1)
     if world > 1:
+        if dist.get_backend(group) != "nccl":
+            total = total.cpu()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return int(total.item())
+
+
+def checksum_weighted(t: torch.Tensor, offset: int = 0, group=None, reduce: bool = True) -> int:
+    """Checksum of a sharded batch that also sees misplaced bytes and frames: the sum over the frames
+    j of this rank's block, numbered globally (`offset` = index of the block's first frame), of
+    (offset + j + 1) * sum_p byte[j, p] * (p mod 65521 + 1), in wrapping int64, summed over the ranks.
+    Equal for every sharding of the same batch; bench.py compares the N-rank value of a fixed-seed
+    batch through Gaussian + rotate with the value the root computes alone."""
+    rank, world = _world(group)
+    total = torch.zeros(1, dtype=torch.int64, device=t.device)
+    if t.shape[0]:
+        flat = t.reshape(t.shape[0], -1)
+        w = torch.arange(flat.shape[1], dtype=torch.int64, device=t.device) % 65521 + 1
+        for j in range(flat.shape[0]):
+            total += (offset + j + 1) * (flat[j].to(torch.int64) * w).sum()
+    if world > 1 and reduce:
+        if dist.get_backend(group) != "nccl":
+            total = total.cpu()                      # host collectives (gloo rehearsal / CPU tests)
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     return int(total.item())

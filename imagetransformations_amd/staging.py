@@ -21,6 +21,8 @@ import numpy as np
 import torch
 
 
+PENDING_BUDGET = 1 << 30   # bytes of asynchronous copies back a batched driver keeps in flight (pinned memory is
+                           # never returned by torch's caching host allocator: the window bounds the footprint)
 SMALL = 256 * 1024      # below this the driver's own small-copy path beats a pinned block + event (32x32 CIFAR images)
 
 

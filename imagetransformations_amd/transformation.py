@@ -331,6 +331,15 @@ def apply_all_transformations_batched_to_files(images, out_dir: str) -> List[str
     return [name for name, _ in named]
 
 
+def _collect(item, results) -> int:
+    """Wait for one queued copy back and build its PIL images; returns the bytes it held."""
+    dl, entries = item
+    host = dl.numpy()
+    for j, (_, i, k) in enumerate(entries):
+        results[i][k] = Image.fromarray(host[j])
+    return host.nbytes
+
+
 def apply_all_transformations_batched_named(images, _sink=None):
     """`apply_all_transformations` with the work grouped for the GPU, returning
     [(file name, image)] in the reference's output order and saving nothing: same draws (`random` per
@@ -371,7 +380,7 @@ def apply_all_transformations_batched_named(images, _sink=None):
         'shear': _shear_t,
         'translation': _translation_t,
     }
-    pending = []                                        # (Download, entries): results still on their way back
+    pending, queued = [], 0                             # (Download, entries): results still on their way back
     for size, members in by_size.items():
         frames = staging.upload([np.asarray(images[i][0]) for i in members], dev)   # one pinned block, async H2D
         groups = {}
@@ -396,11 +405,14 @@ def apply_all_transformations_batched_named(images, _sink=None):
             if _sink is not None:
                 _sink(out, [plans[i][k][2] for _, i, k in entries])
                 continue
-            # queue the copy back and keep launching: the host waits per result only when it builds the images
+            # queue the copy back and keep launching: the host waits per result only when it builds the images.
+            # The window of copies in flight is bounded (staging.PENDING_BUDGET bytes of pinned memory): beyond
+            # it the oldest results are turned into images before the next group is queued
             pending.append((staging.download(out), entries))
-    for dl, entries in pending:
-        host = dl.numpy()
-        for j, (_, i, k) in enumerate(entries):
-            results[i][k] = Image.fromarray(host[j])
+            queued += out.numel()
+            while queued > staging.PENDING_BUDGET and len(pending) > 1:
+                queued -= _collect(pending.pop(0), results)
+    while pending:
+        _collect(pending.pop(0), results)
 
     return [(new_filename, results[i][k]) for i, plan in enumerate(plans) for k, (_, _, new_filename) in enumerate(plan)]

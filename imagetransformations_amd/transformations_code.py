@@ -205,7 +205,7 @@ def apply_all_transformations_batched(images):
         'translation': _translation_t,
         'vert_flip': lambda t: ops.flip(t),
     }
-    pending = []                                        # (Download, entries): results still on their way back
+    pending, queued = [], 0                                      # (Download, entries): results still on their way back
     for size, members in by_size.items():
         frames = staging.upload([np.asarray(images[i][0]) for i in members], dev)     # one pinned block, async H2D
         groups = {}
@@ -238,11 +238,12 @@ def apply_all_transformations_batched(images):
             else:
                 out = tensor_fns[transform_type](batch, *args)
             pending.append((staging.download(out), entries))    # async copy back; the host waits per result below
+            queued += out.numel()
+            while queued > staging.PENDING_BUDGET and len(pending) > 1:      # bounded window of pinned copies in flight
+                queued -= T._collect(pending.pop(0), results)
 
-    for dl, entries in pending:
-        host = dl.numpy()
-        for j, (_, i, k) in enumerate(entries):
-            results[i][k] = Image.fromarray(host[j])
+    while pending:
+        T._collect(pending.pop(0), results)
 
     transformed_images = []
     for i, plan in enumerate(plans):

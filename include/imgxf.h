@@ -66,6 +66,15 @@ const char* imgxf_strerror(int code);
 /* Number of visible HIP devices whose architecture this library was built for (>=0),
  * or a negative error.  Does not create a context on any device. */
 int         imgxf_device_count(void);
+/* The IMGXF_* tuning / routing environment variables are read once, at the first call that needs
+ * one.  This re-reads them (not thread-safe against concurrent launches; for tests and A/B tools
+ * that change a knob inside one process).  No reference counterpart (build infrastructure). */
+int         imgxf_reload_knobs(void);
+/* Measurement aid for bench.py (no reference counterpart): one wave spins for `ticks_100mhz` ticks
+ * of the constant 100 MHz counter and writes {delta s_memtime, delta s_memrealtime} to the two
+ * uint64 at `out2_u64` (device memory); shader clock in MHz = 100 * out[0] / out[1].  Launch it on
+ * a side stream while the kernels of interest run to see the clock they are granted. */
+int         imgxf_probe_sclk(void* out2_u64, unsigned int ticks_100mhz, void* stream);
 
 /* ---- a1: cv2.GaussianBlur(img,(k,k),sigma)  transformation.py:249 -------------------
  * Separable Gaussian, BORDER_REFLECT_101, fp32 accumulate, round-half-even, saturate.

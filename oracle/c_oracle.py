@@ -48,24 +48,26 @@ def set_threads(n: int) -> int:
     return lib().oracle_set_threads(int(n))
 
 
-def gaussian_blur(img: np.ndarray, ksize: int, sigma: float) -> np.ndarray:
+def gaussian_blur(img: np.ndarray, ksize: int, sigma: float, out=None, tmp=None) -> np.ndarray:
+    """`out` / `tmp` (float64, img.size): optional pre-allocated buffers (the timed CPU baseline reuses them
+    so that page faults of fresh 200 MB temporaries are not what it measures)."""
     a = np.ascontiguousarray(img)
     h, w = a.shape[:2]
     c = 1 if a.ndim == 2 else a.shape[2]
-    out = np.empty_like(a)
-    tmp = np.empty(a.size, np.float64)
+    out = np.empty_like(a) if out is None else out
+    tmp = np.empty(a.size, np.float64) if tmp is None else tmp
     rc = lib().oracle_gaussian_blur_u8(_p(a), _p(out), _p(tmp, C.c_double), h, w, c, int(ksize), C.c_double(sigma))
     if rc:
         raise ValueError(f"oracle_gaussian_blur_u8 -> {rc}")
     return out
 
 
-def affine(img: np.ndarray, out_size, m, filter: int, fill=None) -> np.ndarray:
+def affine(img: np.ndarray, out_size, m, filter: int, fill=None, out=None) -> np.ndarray:
     a = np.ascontiguousarray(img)
     h, w = a.shape[:2]
     c = 1 if a.ndim == 2 else a.shape[2]
     ow, oh = out_size
-    out = np.empty((oh, ow) if a.ndim == 2 else (oh, ow, c), np.uint8)
+    out = np.empty((oh, ow) if a.ndim == 2 else (oh, ow, c), np.uint8) if out is None else out
     mm = (C.c_double * 6)(*[float(v) for v in m])
     ff = (C.c_uint8 * 4)(*(list(fill)[:c] + [0] * (4 - min(c, len(fill))))) if fill is not None else None
     rc = lib().oracle_affine_u8(_p(a), h, w, c, _p(out), oh, ow, mm, int(filter), ff)

@@ -75,3 +75,28 @@ def test_motion_blur_full_size_batch(device, monkeypatch):
         monkeypatch.delenv("IMGXF_CONV2D_NO_SEPARABLE")
         dd = (s.int() - d.int()).abs()
         assert int(dd.max()) <= 1 and float((dd != 0).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("k", [13, 17, 21, 31])
+def test_unnormalised_taps_stay_off_the_f16_matrix_cores(device, k):
+    """the f16 matrix-core Gaussian only holds for taps below 2 and row sums below 256
+    (mfma_eligible checks the taps); 2 * ones(k), integer binomial rows and huge row sums must take
+    the vector kernels and satisfy the same fp64 contract (results saturate at 255 / clip at 0)."""
+    from imagetransformations_amd import ops
+    a = synth(170 + k, 96, 352)
+    a[:20] //= 64                                   # small values so that the big taps do not saturate everything
+    t = dev(a, device)
+    cases = [(np.full(k, 2.0), np.full(k, 1.0 / (2 * k * k))),                 # |w| >= 2 on x
+             (np.full(k, 1.0 / (2 * k * k)), np.full(k, 2.5)),                 # ... on y
+             (np.full(k, 30.0), np.full(k, 1.0 / (30.0 * k * k))),             # sum|wx| > 256
+             (np.r_[-3.0, np.zeros(k - 2), 3.0], np.r_[np.zeros(k // 2), 0.25, np.zeros(k // 2)])]
+    for kx, ky in cases:
+        kx32, ky32 = kx.astype(np.float32), ky.astype(np.float32)
+        ref_f = O.conv2d_f64(a, np.outer(ky32.astype(np.float64), kx32.astype(np.float64)))
+        out, f32 = ops.sepconv(t, kx32.tolist(), ky32.tolist(), return_f32=True)
+        got = f32.cpu().numpy()
+        assert np.isfinite(got).all()
+        assert (np.abs(got - ref_f) <= 1e-5 * np.maximum(np.abs(ref_f), 1.0)).all()
+        _check(host(out), ref_f)
+    box2 = 2.0 * np.ones((k, k)) / (k * k)                                   # filter2D form of a rank-1 kernel
+    _check(host(ops.conv2d(t, box2.tolist())), O.conv2d_f64(a, box2))

@@ -70,6 +70,9 @@ def test_bench_distributed_branch_world1_nccl(device):
     assert set(r["resolutions"]) == {"3840x2160", "1920x1080"}
     for k in r["roofline_kernels"].values():
         assert k["ms"]["min"] <= k["ms"]["median"] <= k["ms"]["max"]
+    assert r["checksum_ok"] is True and r["checksum"]["sharded"] == r["checksum"]["single"]
+    assert 400.0 < r["sclk_in_kernel"]["mhz"] < 3000.0            # the in-kernel clock probe (imgxf_probe_sclk)
+    assert r["sclk_mhz"] is None or 90.0 < r["sclk_mhz"]["median"] < 3000.0
 
 
 def test_bench_two_rank_rehearsal_with_scatter_gather_children(device):
@@ -85,6 +88,7 @@ def test_bench_two_rank_rehearsal_with_scatter_gather_children(device):
     assert r["n_gpus"] == 2 and r["config"]["global_frames"] == 8 and r["scaling"] == "weak"
     sg = r["scatter_gather"]
     assert sg.get("equal") is True and sg["frames"] == 16, sg
+    assert r["checksum_ok"] is True, r.get("checksum")           # sharded result == the root's single-GPU result
 
 
 def test_ops_follow_the_tensors_device_and_stream(device):

@@ -100,3 +100,66 @@ def test_pipelined_map_equals_plain_world2(tmp_path, n_frames, chunk):
     want = np.stack([O.rgb2l(f) for f in res["inp"]])
     assert np.array_equal(res["piped"], want)
     assert np.array_equal(res["plain"], want)
+
+
+def _worker_edges(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from imagetransformations_amd import sharding as S
+        cpu = torch.device("cpu")
+        calls = []
+
+        def to_l(block):          # changes the frame geometry (RGB -> L) and records what it was run on
+            calls.append(int(block.shape[0]))
+            return torch.from_numpy(np.stack([O.rgb2l(f.numpy()) for f in block]))
+
+        # (a) an empty batch: the root gets an empty tensor like map_frames, not None
+        empty = torch.zeros((0, 20, 28, 3), dtype=torch.uint8) if rank == 0 else None
+        e1 = S.map_frames_pipelined(to_l, empty, 0, (20, 28, 3), cpu, chunk=2, out_shape=(20, 28))
+        assert (e1 is not None and tuple(e1.shape) == (0, 20, 28)) if rank == 0 else e1 is None
+        assert calls == []
+        # (b) root = 1 with ONE frame: rank 0 owns it, the root's block is empty; fn never runs on the root and
+        # the output geometry reaches the root from rank 0 (no out_shape given) or from the caller
+        one = torch.from_numpy(synth(91, 20, 28))[None] if rank == 1 else None
+        got = S.map_frames_pipelined(to_l, one, 1, (20, 28, 3), cpu, chunk=4, root=1)
+        got2 = S.map_frames_pipelined(to_l, one, 1, (20, 28, 3), cpu, chunk=4, root=1, out_shape=(20, 28))
+        assert calls == ([1, 1] if rank == 0 else [])
+        # (c) a sub-group whose group ranks differ from the global ranks (group [1, 2]: group rank 0 = global 1)
+        grp = dist.new_group([1, 2])
+        sub = sub_plain = None
+        if rank in (1, 2):
+            frames = torch.from_numpy(np.stack([synth(60 + i, 20, 28) for i in range(5)])) if dist.get_rank(grp) == 0 else None
+            sub = S.map_frames_pipelined(to_l, frames, 5, (20, 28, 3), cpu, chunk=2, group=grp)
+            sub_plain = S.map_frames(to_l, frames, 5, (20, 28, 3), cpu, group=grp)
+        # (d) the weighted checksum is independent of the sharding and sees a swap of two frames
+        full = torch.from_numpy(np.stack([synth(70 + i, 20, 28) for i in range(5)]))
+        a, b = S.shard_range(5, world, rank)
+        sharded = S.checksum_weighted(full[a:b], offset=a)
+        swapped = full.clone(); swapped[[0, 4]] = swapped[[4, 0]]
+        sharded_swapped = S.checksum_weighted(swapped[a:b], offset=a)
+        byte_sum = S.checksum(full[a:b])
+        if rank == 1:
+            w = np.arange(20 * 28 * 3, dtype=np.int64) % 65521 + 1
+            alone = sum((j + 1) * int((full[j].numpy().reshape(-1).astype(np.int64) * w).sum()) for j in range(5))
+            np.savez(out_path, got=got.numpy(), got2=got2.numpy(), want=O.rgb2l(one[0].numpy()),
+                     sub=sub.numpy() if sub is not None else np.zeros(0),
+                     sub_plain=sub_plain.numpy() if sub_plain is not None else np.zeros(0),
+                     sub_want=np.stack([O.rgb2l(synth(60 + i, 20, 28)) for i in range(5)]),
+                     sharded=sharded, alone=alone, sharded_swapped=sharded_swapped, byte_sum=byte_sum)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_edges_empty_root_block_empty_batch_subgroup_world3(tmp_path):
+    """ADVICE r2 (sharding.py): an empty batch returns an empty tensor on the root; a root that owns no frame never
+    runs fn (the geometry comes from rank 0 or `out_shape`); peers of a sub-group are addressed by global rank; the
+    position-weighted checksum does not depend on the sharding and, unlike the byte sum, sees swapped frames."""
+    out_path = str(tmp_path / "edges.npz")
+    mp.spawn(_worker_edges, args=(3, _free_port(), out_path), nprocs=3, join=True)
+    res = np.load(out_path)
+    assert np.array_equal(res["got"][0], res["want"]) and np.array_equal(res["got2"][0], res["want"])
+    assert np.array_equal(res["sub"], res["sub_want"]) and np.array_equal(res["sub_plain"], res["sub_want"])
+    assert int(res["sharded"]) == int(res["alone"]) != int(res["sharded_swapped"])
+    assert int(res["byte_sum"]) == sum(int(synth(70 + i, 20, 28).astype(np.int64).sum()) for i in range(5))

@@ -31,6 +31,7 @@ def run(v, precise, iters=5):
     os.environ["IMGXF_AFFINE_FPB"] = fpb
     if nodma: os.environ["IMGXF_AFFINE_NO_DMA"] = "1"
     else: os.environ.pop("IMGXF_AFFINE_NO_DMA", None)
+    __import__("imagetransformations_amd")._ffi.reload_knobs()   # the library caches its knobs
     call = lambda: _ffi.call("imgxf_affine_u8", _ffi.vp(vs), _ffi.vp(vo), m, 1, fill, precise, None, st)
     call(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

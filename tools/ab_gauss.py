@@ -36,6 +36,7 @@ if extra:      # e.g. AB_EXTRA="rpw180:IMGXF_MARCH_RPW=180"
 def run(env, iters=10):
     for k in KNOBS: os.environ.pop(k, None)
     os.environ.update(env)
+    __import__("imagetransformations_amd")._ffi.reload_knobs()   # the library caches its knobs
     call = lambda: _ffi.call("imgxf_gaussian_u8", _ffi.vp(vs), _ffi.vp(vo), 5, 5 / 6, None, st)
     call(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

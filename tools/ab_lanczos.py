@@ -15,6 +15,7 @@ frames = torch.randint(0, 256, (F, H, W, 3), dtype=torch.uint8, device=dev, gene
 def run(scale, no_mfma, iters=6):
     if no_mfma: os.environ["IMGXF_RESAMPLE_NO_MFMA"] = "1"
     else: os.environ.pop("IMGXF_RESAMPLE_NO_MFMA", None)
+    __import__("imagetransformations_amd")._ffi.reload_knobs()   # the library caches its knobs
     call = lambda: _scale_t(frames, scale)      # > 1: resize + centre crop; < 1: resize into a black canvas
     call(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

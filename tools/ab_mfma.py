@@ -15,6 +15,7 @@ st = torch.cuda.current_stream().cuda_stream
 vs, vo = _ffi.view_of(frames), _ffi.view_of(out)
 def run(k, sigma, minr, iters=4):
     os.environ["IMGXF_MFMA_MIN_R"] = str(minr)
+    __import__("imagetransformations_amd")._ffi.reload_knobs()   # the library caches its knobs
     call = lambda: _ffi.call("imgxf_gaussian_u8", _ffi.vp(vs), _ffi.vp(vo), k, sigma, None, st)
     call(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

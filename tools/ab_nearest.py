@@ -13,6 +13,7 @@ frames = torch.randint(0, 256, (F, H, W, 3), dtype=torch.uint8, device=dev, gene
 def run(strips, angle, iters=6):
     if strips: os.environ.pop("IMGXF_AFFINE_NO_STRIPS", None)
     else: os.environ["IMGXF_AFFINE_NO_STRIPS"] = "1"
+    __import__("imagetransformations_amd")._ffi.reload_knobs()   # the library caches its knobs
     call = lambda: ops.rotate(frames, angle, ops.NEAREST, (0, 0, 0))
     call(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
