@@ -1290,6 +1290,7 @@ static int launch_affine_filter(int filter, const View& s, const View& d, const 
 
 } // namespace imgxf
 #include "affine_mf.inc"
+#include "affine_wq.inc"
 namespace imgxf {
 
 // Tall interior tiles: `affine_bilinear_lds_interior_kernel<.., BHT>` over every 32 x BHT tile (the
@@ -1320,6 +1321,47 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
     const bool dma = mf && !knob_set(K_AFFINE_NO_DMA) && bht <= 52 && bwt <= 52 && 52 * nch <= 768 &&
                      ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs) & 15) == 0 && s.w * 3 >= 16 &&
                      (int64_t)s.h * s.rs < ((int64_t)1 << 32);
+    // round 3: wave-private boxes + whole-line stores (affine_wq.inc) when a 32 x 16 block's box fits 28 x 27 pixels
+    // and both images are 16-byte aligned with 16-byte multiples as rows
+    if (mf && !knob_set(K_AFFINE_NO_WQ) && !knob_set(K_AFFINE_NO_DMA)) {
+        const int bwq = (int)ceil(fabs(m[0]) * 31 + fabs(m[1]) * 15) + 4, bhq = (int)ceil(fabs(m[3]) * 31 + fabs(m[4]) * 15) + 4;
+        const int nchq = (bwq * 3 + 15 + 15) / 16;
+        const int ntxq = (d.w + 127) / 128, ntyq = (d.h + 15) / 16;
+        const bool aligned = ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | ((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs) & 15) == 0 &&
+                             (d.w * 3) % 16 == 0 && s.w * 3 >= 16;
+        if (aligned && bwq <= WQ_PITCH && bhq * nchq <= WQ_MAXCH && bhq * (WQ_PITCH / 4) <= 192 &&
+            (int64_t)s.h * s.rs < ((int64_t)1 << 32) && (int64_t)ntxq * ntyq < ((int64_t)1 << 27)) {
+            AffineParams Pq = Pin;
+            Pq.strip_w = 0;
+            dim3 grid((unsigned)(ntxq * ntyq), (unsigned)((d.n + afpb - 1) / afpb));
+            if (ntxq >= 16 && !knob_set(K_AFFINE_NO_STRIPS)) { Pq.strip_w = (ntxq + 7) / 8; grid.x = (unsigned)(8 * Pq.strip_w * ntyq); }
+            const size_t lds = (size_t)4 * ((size_t)bhq * WQ_PITCH * 4 + 2 * ((size_t)bhq * nchq * 16 + 64)) + 2 * 16 * 384;
+            if (pr) hipLaunchKernelGGL((affine_bilinear_wq_kernel<true>), grid, dim3(256), lds, st, s, d, Pq, ntxq, ntyq, fpb, nchq, bhq, knob_int(K_AFFINE_MF_DBG, 0));
+            else hipLaunchKernelGGL((affine_bilinear_wq_kernel<false>), grid, dim3(256), lds, st, s, d, Pq, ntxq, ntyq, fpb, nchq, bhq, knob_int(K_AFFINE_MF_DBG, 0));
+            return launch_status();
+        }
+    }
+    // (64 x 32 tiles, IMGXF_AFFINE_MF_WIDE: 192-byte rows; measured slower than 32 x 64 — 1.76 vs 1.63 ms — although their
+    // stores alone are faster: kept as an experiment knob)
+    if (dma && knob_set(K_AFFINE_MF_WIDE) && !knob_set(K_AFFINE_MF_NARROW)) {
+        // 64 x 32 tiles when THEIR source box fits the same LDS image: 192-byte output rows (two of three 128-byte lines
+        // written whole by one workgroup) instead of 96-byte ones — see affine_mf.inc, WIDE
+        const int bww = (int)ceil(fabs(m[0]) * 63 + fabs(m[1]) * 31) + 4, bhw = (int)ceil(fabs(m[3]) * 63 + fabs(m[4]) * 31) + 4;
+        const int nchw = (bww * 3 + 15 + 15) / 16;
+        const int ntxw = (d.w + 63) / 64, ntyw = (d.h + 31) / 32;
+        if (bww <= 52 && bhw <= 52 && 52 * nchw <= 768 && (int64_t)ntxw * ntyw < ((int64_t)1 << 28)) {
+            dim3 grid((unsigned)(ntxw * ntyw), (unsigned)((d.n + afpb - 1) / afpb));
+            const int npk = knob_set(K_AFFINE_PK3) ? 3 : 2;
+            AffineParams Ps = Pin;
+            Ps.ntx_magic = (u32)((((uint64_t)1 << 32) + ntxw - 1) / ntxw);
+            if (ntxw == 1) Ps.ntx_magic = 0;
+            if (ntxw >= 16 && !knob_set(K_AFFINE_NO_STRIPS)) { Ps.strip_w = (ntxw + 7) / 8; grid.x = (unsigned)(8 * Ps.strip_w * ntyw); }
+            const size_t lds = (size_t)52 * 56 * 4 + npk * ((size_t)52 * nchw * 16 + 64);
+            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, 56, 13, true, true>), grid, dim3(256), lds, st, s, d, Ps, ntxw, ntyw, fpb, nchw, npk, knob_int(K_AFFINE_MF_DBG, 0));
+            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, 56, 13, true, true>), grid, dim3(256), lds, st, s, d, Ps, ntxw, ntyw, fpb, nchw, npk, knob_int(K_AFFINE_MF_DBG, 0));
+            return launch_status();
+        }
+    }
     if (dma) {
         dim3 grid((unsigned)(ntx * ntyt), (unsigned)((d.n + afpb - 1) / afpb));
         // RGBX pitch 56: fewest bank conflicts of the multiples of 4 (simulated for 30 deg / 1.5x: 4.0 vs 5.8 LDS cycles per gather read at 52)
@@ -1327,8 +1369,8 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
         AffineParams Ps = Pin;
         if (ntx >= 16 && !knob_set(K_AFFINE_NO_STRIPS)) { Ps.strip_w = (ntx + 7) / 8; grid.x = (unsigned)(8 * Ps.strip_w * ntyt); }
         const size_t lds = (size_t)52 * 56 * 4 + npk * ((size_t)52 * nch * 16 + 64);
-        if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, 56, 13, true>), grid, dim3(256), lds, st, s, d, Ps, ntx, ntyt, fpb, nch, npk);
-        else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, 56, 13, true>), grid, dim3(256), lds, st, s, d, Ps, ntx, ntyt, fpb, nch, npk);
+        if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, 56, 13, true>), grid, dim3(256), lds, st, s, d, Ps, ntx, ntyt, fpb, nch, npk, knob_int(K_AFFINE_MF_DBG, 0));
+        else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, 56, 13, true>), grid, dim3(256), lds, st, s, d, Ps, ntx, ntyt, fpb, nch, npk, knob_int(K_AFFINE_MF_DBG, 0));
         return launch_status();
     }
     // the kernel's interior test (bilinear_tile<.., BHT, true>) with the same integers
@@ -1355,11 +1397,11 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
         const dim3 grid((unsigned)(ntx * ntyt), (unsigned)((d.n + afpb - 1) / afpb));
         const size_t lds = (size_t)2 * PITCH * (bht <= 52 ? 52 : 64) * 4 + 16;     // all 4 * NBR rows are written
         if (bht <= 52) {
-            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0);
-            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0);
+            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0, 0);
+            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 13, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0, 0);
         } else {
-            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0);
-            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0);
+            if (pr) hipLaunchKernelGGL((affine_bilinear_mf_kernel<true, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0, 0);
+            else hipLaunchKernelGGL((affine_bilinear_mf_kernel<false, PITCH, 16, false>), grid, dim3(256), lds, st, s, d, P, ntx, ntyt, fpb, 0, 0, 0);
         }
         IMGXF_CHECK(launch_status());
     } else if (list.n < ntx * ntyt) {                // at least one interior tile

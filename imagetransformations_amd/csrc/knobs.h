@@ -5,7 +5,7 @@
 
 #define IMGXF_KNOB_LIST(X)                                                                          \
     X(AFFINE_FPB) X(AFFINE_NO_DMA) X(AFFINE_NO_LDS) X(AFFINE_NO_SHEAR_FAST) X(AFFINE_NO_STRIPS)      \
-    X(AFFINE_NO_TALL) X(AFFINE_PK3) X(AFFINE_TILE) X(AFFINE_MF_V1) X(BOX_BYTES) X(CONV2D_NO_SEPARABLE) \
+    X(AFFINE_NO_TALL) X(AFFINE_PK3) X(AFFINE_TILE) X(AFFINE_MF_DBG) X(AFFINE_MF_NARROW) X(AFFINE_NO_WQ) X(AFFINE_MF_WIDE) X(BOX_BYTES) X(CONV2D_NO_SEPARABLE) \
     X(FILTER3X3_BYTES) X(FX_MFMA_MIN_R) X(LANCZOS_NO_LDS) X(LANCZOS_NO_V4) X(LANCZOS_SLOW)           \
     X(MARCH4_NO_PX) X(MARCH_GROUP) X(MARCH_NO_MIXED) X(MARCH_RPW) X(MARCH_SPB) X(MARCH_TAIL)         \
     X(MARCH_U2) X(MARCH_ORDER) X(MFMA2_BPC) X(MFMA_MIN_R) X(MFMA_NO_HREG) X(MFMA_SHAPE) X(MFMA_V1)   \

@@ -43,6 +43,15 @@ def test_batched_bilinear_frames_per_block_and_views(device, monkeypatch):
         monkeypatch.setenv("IMGXF_AFFINE_FPB", fpb)
         assert np.array_equal(host(ops.affine(t, m, (w, h), ops.BILINEAR, (9, 8, 7), precise=True)), want), fpb
     monkeypatch.delenv("IMGXF_AFFINE_FPB")
+    # round 3: 64 x 32 tiles are the default when their source box fits; the 32 x 64 tiles stay behind a knob (and
+    # serve geometries whose wide box is too large)
+    monkeypatch.setenv("IMGXF_AFFINE_MF_NARROW", "1")
+    assert np.array_equal(host(ops.affine(t, m, (w, h), ops.BILINEAR, (9, 8, 7), precise=True)), want)
+    for mm in _matrices(w, h):
+        got = host(ops.affine(t[:3], mm, (w, h), ops.BILINEAR, (0, 0, 0), precise=True))
+        for i in range(3):
+            assert np.array_equal(got[i], O.affine_bilinear(a[i], (w, h), mm, fill=(0, 0, 0))), ("narrow", mm, i)
+    monkeypatch.delenv("IMGXF_AFFINE_MF_NARROW")
     # every other frame of a larger batch (frame stride = 2 frames)
     big = dev(np.stack([synth(740 + i, h, w) for i in range(8)]), device)
     got = host(ops.affine(big[::2], m, (w, h), ops.BILINEAR, (0, 0, 0), precise=True))

@@ -57,6 +57,18 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
             if (KIND == 39) asm volatile("v_cmp_lt_u32 s[20:21], %1, %2\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]) : "s20", "s21");
             if (KIND == 40) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(u[(i + 1) % CHAINS]), "v"(seed));
             if (KIND == 41) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(u[(i + 1) % CHAINS]), "v"(seed));
+            if (KIND == 42) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
+            if (KIND == 43) asm volatile("v_alignbit_b32 %0, %1, %1, 15" : "=v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 44) asm volatile("v_lshl_add_u32 %0, %0, 8, %1" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 45) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
+            if (KIND == 46) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) % CHAINS]));
+            if (KIND == 47) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 48) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(dd[i]) : "v"(dd[(i + 1) % CHAINS]));
+            if (KIND == 49) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 50) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 51) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(a[i]) : "v"(u[(i + 1) % CHAINS]));
+            if (KIND == 52) asm volatile("v_cvt_u32_f32 %0, %1" : "=v"(u[i]) : "v"(a[(i + 1) % CHAINS]));
+            if (KIND == 53) asm volatile("v_lshlrev_b32 %0, 1, %1" : "=v"(u[i]) : "v"(u[(i + 1) % CHAINS]));
             if (KIND == 27) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) % CHAINS]), "v"(u[(i + 2) % CHAINS]));
         }
     }
@@ -90,5 +102,8 @@ int main() {
     run<28>("v_cndmask_b32_e64 sgpr"); run<29>("v_cndmask_b32_e32 vcc"); run<30>("v_sub_f32"); run<31>("v_mul_f32"); run<32>("v_and_b32");
     run<38>("cmp+cndmask via vcc (2 instr)"); run<39>("cmp+cndmask via sgpr pair (2 instr)");
     run<33>("v_lshrrev_b32"); run<34>("v_max_f32"); run<35>("v_mov_b32"); run<36>("v_or_b32"); run<37>("v_fmac_f32");
+    run<42>("v_min3_u32"); run<43>("v_alignbit_b32 rot"); run<44>("v_lshl_add_u32"); run<45>("v_and_or_b32"); run<46>("v_add_f32");
+    run<47>("v_pk_min_u16"); run<48>("v_pk_add_f32"); run<49>("v_xor_b32"); run<50>("v_sub_u32"); run<51>("v_cvt_f32_u32"); run<52>("v_cvt_u32_f32");
+    run<53>("v_lshlrev_b32 1");
     return 0;
 }
