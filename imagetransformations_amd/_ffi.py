@@ -69,6 +69,8 @@ SIGNATURES = {
     "imgxf_scale_abs_u8": [_VP, _VP, C.c_float, C.c_float, C.c_void_p],
     "imgxf_blend_u8": [_VP, _U8, _VP, _U8, _VP, C.c_float, C.c_void_p],
     "imgxf_add_noise_u8": [_VP, _VP, _VP, C.c_void_p],
+    "imgxf_add_noise_philox_u8": [_VP, _VP, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p],
+    "imgxf_philox4x32_u32": [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p],
     "imgxf_permute_u8": [_VP, _VP, _I32, C.c_void_p],
     "imgxf_composite_u8": [_VP, _VP, _VP, _VP, C.c_void_p],
     "imgxf_composite_const_u8": [_VP, _U8, _VP, _VP, C.c_void_p],

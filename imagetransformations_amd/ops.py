@@ -539,6 +539,27 @@ def add_noise(t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def add_noise_device(t: torch.Tensor, sigma: float, seed: int, offset: int = 0) -> torch.Tensor:
+    """apply_gaussian_noise with the normals generated on the device (Philox4x32-10 + Box-Muller):
+    clip(f32(p) + N(0, sigma), 0, 255) truncated; `sigma` = noise_std * 255.  Not NumPy's stream — the
+    opt-in IMGXF_NOISE_RNG=device path of the facade.  Element e of the batch uses normal number offset + e."""
+    t = _check_u8(t)
+    out = torch.empty_like(t, memory_format=torch.contiguous_format)
+    _launch(t, "imgxf_add_noise_philox_u8", F.vp(F.view_of(t)), F.vp(F.view_of(out)), float(sigma),
+            int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset))
+    return out
+
+
+def philox_u32(count: int, seed: int, offset: int = 0, device=None) -> torch.Tensor:
+    """`count` (multiple of 4) raw Philox4x32-10 words as an int32 tensor (bit pattern of the uint32 stream)."""
+    device = torch.device("cuda") if device is None else torch.device(device)
+    out = torch.empty((count,), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        F.call("imgxf_philox4x32_u32", out.data_ptr(), int(count), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset),
+               torch.cuda.current_stream(device).cuda_stream)
+    return out
+
+
 def add_noise_f64(t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
     """np.clip(img.astype(f32) + noise_f64, 0, 255).astype(u8) — cifar_image_transformations.py:45-47."""
     t = _check_u8(t)

@@ -194,6 +194,16 @@ int imgxf_blend_u8(const imgxf_view* im1, const uint8_t* color1, const imgxf_vie
 /* transformation.py:275-278: clip(f32(p)+noise,0,255) truncated; noise: float view, same n,h,w,c. */
 int imgxf_add_noise_u8(const imgxf_view* src, const imgxf_view* noise_f32, const imgxf_view* dst,
                        void* stream);
+/* The same step with the noise tensor GENERATED ON THE DEVICE (opt-in, IMGXF_NOISE_RNG=device in the facade): the host's
+ * np.random.normal(0, sigma, shape).astype(f32) at transformation.py:274 is replaced by Philox4x32-10 (key = seed,
+ * counter = offset / 4 + element index / 4) + Box-Muller in fp32, scaled by `sigma` (= noise_std * 255); then
+ * clip(f32(p) + noise, 0, 255) truncated as above.  A different random stream than NumPy's MT19937: distribution-level
+ * parity only.  `offset` (a multiple of 4) numbers the first normal of this call, so frames of one
+ * logical batch can be processed in several calls with identical results.  In-place ok. */
+int imgxf_add_noise_philox_u8(const imgxf_view* src, const imgxf_view* dst, float sigma, uint64_t seed,
+                              uint64_t offset, void* stream);
+/* The raw uint32 stream behind it (tests: Random123 known-answer vectors): count (multiple of 4) values to dst_u32. */
+int imgxf_philox4x32_u32(void* dst_u32, int64_t count, uint64_t seed, uint64_t offset, void* stream);
 /* cv2.cvtColor channel permutations (RGB2BGR, RGBA2RGB, ...) transformation.py:206,233-235,252:
  * dst[..., j] = src[..., perm[j]] for j < dst->c.  perm: HOST pointer. */
 int imgxf_permute_u8(const imgxf_view* src, const imgxf_view* dst, const int32_t* perm,

@@ -61,13 +61,35 @@ __global__ __launch_bounds__(256) void writek(u32x4* __restrict__ b, size_t n) {
 // instructions per row (dependent fmacs on the loaded data) to emulate an issue-bound body.
 template <int J, bool HALO, bool NT, int WORK, int AUX = 0>
 __global__ __launch_bounds__(768) void marchk(const u8* __restrict__ src, u8* __restrict__ dst, int h, int64_t rs, int64_t fs,
-                                              int rows_per_wave, int nchunks, int gx, int G, int bpr) {
+                                              int rows_per_wave, int nchunks, int gx, int G, int bpr, int order = 0) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int SLOT = 1024 + 32;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
     const int logical = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
-    const int bx = logical % gx, chunk = (logical / gx) % nchunks, f = (logical / (gx * nchunks)) * G;
+    int bx = logical % gx, chunk = (logical / gx) % nchunks, f = (logical / (gx * nchunks)) * G;
+    // work orders (round 3): which (strip, chunk, frame group) does workgroup id `orig` take?
+    //  0  XCD-contiguous ranges, strips fastest, then chunks, then frame groups (the shipped order)
+    //  1  every XCD works on the SAME frame group: XCD k owns the chunks k, k+8, k+16, ... of it
+    //  2  plain row-major ids (no XCD decode)
+    //  3  XCD-contiguous ranges, chunks fastest, then strips
+    //  4  XCD-contiguous ranges, frame groups fastest (the same rows of many frames are in flight)
+    //  5  every XCD works on the same frame group: XCD k owns a contiguous band of chunks of it
+    if (order != 0) {
+        const int cpx = (nchunks + 7) / 8, l = orig >> 3, ngroups = nwg / (8 * gx * cpx);
+        if (order == 1 || order == 5) {
+            bx = l % gx; const int c8 = (l / gx) % cpx; f = (l / (gx * cpx)) * G;
+            chunk = order == 1 ? c8 * 8 + xcd : xcd * cpx + c8;
+            if (chunk >= nchunks || l / (gx * cpx) >= ngroups) return;
+        } else if (order == 2) {
+            bx = orig % gx; chunk = (orig / gx) % nchunks; f = (orig / (gx * nchunks)) * G;
+        } else if (order == 3) {
+            chunk = logical % nchunks; bx = (logical / nchunks) % gx; f = (logical / (gx * nchunks)) * G;
+        } else if (order == 4) {
+            const int ng = nwg / (gx * nchunks);
+            f = (logical % ng) * G; bx = (logical / ng) % gx; chunk = logical / (ng * gx);
+        }
+    }
     const int total = G * bpr;
     const int strip = bx * (blockDim.x >> 6) + wave;
     if (strip * 64 >= total) return;
@@ -143,7 +165,7 @@ template <class Fn> static float timeit(Fn fn, int iters = 8) {
 struct Geo { int n, h; int64_t rs, fs; };
 
 template <int J, bool HALO, bool NT, int WORK, int AUX = 0>
-static void run_march(const char* tag, const u8* a, u8* b, Geo g, int G, int spb, int rpw, int pad_lds = 0) {
+static void run_march(const char* tag, const u8* a, u8* b, Geo g, int G, int spb, int rpw, int pad_lds = 0, int order = 0) {
     const int bpr = (int)(g.rs / 16);
     const int nstrips = (G * bpr + 63) / 64;
     const int gx = (nstrips + spb - 1) / spb;
@@ -151,10 +173,11 @@ static void run_march(const char* tag, const u8* a, u8* b, Geo g, int G, int spb
     const int rpw2 = (g.h + nchunks - 1) / nchunks;
     const int groups = g.n / G;
     const size_t lds = (size_t)spb * (16 + J * 1056) + pad_lds;
-    const unsigned nwg = (unsigned)(gx * nchunks * groups);
+    const unsigned nwg = (order == 1 || order == 5) ? (unsigned)(8 * gx * ((nchunks + 7) / 8) * groups) : (unsigned)(gx * nchunks * groups);
     float ms = timeit([&] {
-        hipLaunchKernelGGL((marchk<J, HALO, NT, WORK, AUX>), dim3(nwg), dim3(64 * spb), lds, 0, a, b, g.h, g.rs, g.fs, rpw2, nchunks, gx, G, bpr);
+        hipLaunchKernelGGL((marchk<J, HALO, NT, WORK, AUX>), dim3(nwg), dim3(64 * spb), lds, 0, a, b, g.h, g.rs, g.fs, rpw2, nchunks, gx, G, bpr, order);
     });
+    if (order) printf("order %d  ", order);
     const double bytes = 2.0 * g.n * g.h * g.rs;
     printf("march %-22s aux=%-2d lds=%-6zu J=%d halo=%d nt=%d work=%-3d G=%d spb=%d rpw=%-4d wgs=%-6u %7.3f ms %7.1f GB/s\n", tag, AUX, lds, J, (int)HALO, (int)NT, WORK, G, spb,
            rpw2, nwg, ms, bytes / ms / 1e6);
@@ -197,6 +220,18 @@ int main(int argc, char** argv) {
             run_march<5, true, true, 35, 2>("G1 work140 nt", a, b, g, 1, 4, 94);
             run_march<5, true, true, 50, 2>("G1 work200 nt", a, b, g, 1, 4, 94);
             run_march<5, true, true, 50, 0>("G1 work200", a, b, g, 1, 4, 94);
+            printf("----\n");
+            continue;
+        }
+        if (getenv("SKEL_ORDER")) {
+            // the shipped launch shape (super-rows of 4 frames, single-wave workgroups, 64-row chunks) and the
+            // full-row-workgroup shape (all 45 strips of a super-row in one workgroup... 12 strips of one frame) in every order
+            for (int order : {0, 1, 5, 2, 3, 4}) run_march<5, true, true, 0>("G4 spb1 rpw64", a, b, g, 4, 1, 64, 0, order);
+            for (int order : {0, 1, 5, 2, 3, 4}) run_march<5, true, true, 0>("G1 spb12 rpw64", a, b, g, 1, 12, 64, 0, order);
+            for (int order : {0, 1, 5, 3}) run_march<5, true, true, 0>("G4 spb9 rpw64", a, b, g, 4, 9, 64, 0, order);
+            for (int order : {0, 1, 5}) run_march<5, true, true, 0>("G4 spb1 rpw32", a, b, g, 4, 1, 32, 0, order);
+            for (int order : {0, 1, 5}) run_march<5, true, true, 0>("G4 spb1 rpw135", a, b, g, 4, 1, 135, 0, order);
+            for (int order : {0, 1, 5}) run_march<5, true, true, 35>("G4 spb1 rpw64 work140", a, b, g, 4, 1, 64, 0, order);
             printf("----\n");
             continue;
         }
