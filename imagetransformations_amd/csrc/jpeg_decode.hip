@@ -1,0 +1,313 @@
+// Baseline JPEG reader on the device: the decode half of the reference's load step `Image.open(path).convert("RGB")`
+// (/root/reference/transformation.py:83), bit-identical to Pillow / libjpeg-turbo with its defaults.
+//
+// The host (imagetransformations_amd/jpeg.py) parses the markers, removes the byte stuffing, splits the scan at RSTn
+// markers and derives the decoding tables; three kernels do the rest:
+//
+//   jpeg_huff_kernel    entropy decoding (jdhuff.c decode_mcu): one THREAD per restart segment, one workgroup per image.
+//                       Huffman decoding is the serial direction: a file without restart markers (every file Pillow
+//                       writes by default, every ImageNet file) is ONE segment, so the parallelism of this stage is the
+//                       number of files in the batch.  8-bit lookahead tables in LDS, canonical maxcode / valoff walk for
+//                       longer codes, a 64-bit bit buffer refilled four bytes at a time, coefficients scattered to their
+//                       natural-order slots (the buffer is zero on entry).
+//   jpeg_idct_kernel    dequantisation + jidctint.c jpeg_idct_islow: 8 threads per block (a column each, then a row each,
+//                       through LDS), the masked range-limit table as arithmetic.
+//   jpeg_color_kernel   jdsample.c fullsize / h2v1_fancy / h2v2_fancy upsampling (edge replication as jdmainct.c does)
+//                       + jdcolor.c ycc_rgb_convert in its 16-bit fixed point, or gray -> RGB; 4 pixels per thread.
+#include "imgxf_common.h"
+
+namespace imgxf {
+
+__constant__ u8 kDecZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,
+                                  7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
+                                  39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+typedef uint32_t u32_una __attribute__((aligned(1)));
+
+struct BitReader {
+    const u8* p;            // segment bytes (stuffing removed)
+    int len, pos;           // bytes, next byte to load
+    uint64_t acc;           // next bits, left aligned
+    int nb;                 // valid bits in acc
+    __device__ __forceinline__ void refill() {
+        // four bytes at a time while there is room; past the end of the segment zero bits are fed (jdhuff.c does the
+        // same after its "premature end of data" warning) — the caller notices through pos > len + 8
+        while (nb <= 32) {
+            u32 w = 0;
+            if (pos + 4 <= len) w = __builtin_bswap32(*(const u32_una*)(p + pos));
+            else for (int i = 0; i < 4; ++i) w = (w << 8) | (pos + i < len ? p[pos + i] : 0u);
+            acc |= (uint64_t)w << (32 - nb);
+            nb += 32; pos += 4;
+        }
+    }
+    __device__ __forceinline__ u32 peek(int n) const { return (u32)(acc >> (64 - n)); }
+    __device__ __forceinline__ void skip(int n) { acc <<= n; nb -= n; }
+};
+
+// one Huffman symbol: 8-bit lookahead in LDS, then the canonical walk of jdhuff.c (jpeg_huff_decode) in global memory
+__device__ __forceinline__ int huff_symbol(BitReader& br, const uint16_t* look, const imgxf_jpeg_dec_lut* lut, bool& bad) {
+    const u32 e = look[br.peek(8)];
+    if (e) { br.skip((int)(e >> 8)); return (int)(e & 0xffu); }
+    for (int l = 9; l <= 16; ++l) {
+        const int code = (int)br.peek(l);
+        if (code <= lut->maxcode[l]) { br.skip(l); return lut->huffval[(code + lut->valoff[l]) & 0xff]; }
+    }
+    bad = true;
+    br.skip(16);
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void jpeg_huff_kernel(const u8* __restrict__ scan, const int64_t* __restrict__ seg_off,
+                                                       const int32_t* __restrict__ seg_len, const imgxf_jpeg_dec_image* __restrict__ images,
+                                                       const imgxf_jpeg_dec_lut* __restrict__ luts, int16_t* __restrict__ coefs,
+                                                       int32_t* __restrict__ status) {
+    __shared__ uint16_t look[6][256];
+    const imgxf_jpeg_dec_image& im = images[blockIdx.x];
+    for (int i = threadIdx.x; i < 6 * 256; i += 64) {
+        const int slot = i >> 8, c = slot >> 1;
+        if (c < im.ncomp) look[slot][i & 255] = luts[(slot & 1) ? im.comp[c].ac_tab : im.comp[c].dc_tab].look[i & 255];
+    }
+    __syncthreads();
+    const int total = im.mcux * im.mcuy;
+    bool bad = false;
+    for (int s = threadIdx.x; s < im.seg_count; s += 64) {
+        BitReader br;
+        br.p = scan + seg_off[im.seg_first + s]; br.len = seg_len[im.seg_first + s]; br.pos = 0; br.acc = 0; br.nb = 0;
+        int pred[3] = {0, 0, 0};
+        const int m0 = s * im.restart_interval, m1 = min(total, m0 + im.restart_interval);
+        int my = m0 / im.mcux, mx = m0 - my * im.mcux;
+        for (int m = m0; m < m1; ++m) {
+            for (int c = 0; c < im.ncomp; ++c) {
+                const imgxf_jpeg_dec_comp& cp = im.comp[c];
+                const imgxf_jpeg_dec_lut* ldc = luts + cp.dc_tab;
+                const imgxf_jpeg_dec_lut* lac = luts + cp.ac_tab;
+                for (int by = 0; by < cp.v; ++by)
+                    for (int bx = 0; bx < cp.h; ++bx) {
+                        int16_t* blk = coefs + cp.coef_off + ((int64_t)(my * cp.v + by) * cp.blocks_x + (mx * cp.h + bx)) * 64;
+                        br.refill();
+                        int sz = huff_symbol(br, look[2 * c], ldc, bad) & 15;
+                        if (sz) {
+                            br.refill();
+                            int v = (int)br.peek(sz); br.skip(sz);
+                            if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
+                            pred[c] += v;
+                        }
+                        if (pred[c]) blk[0] = (int16_t)pred[c];
+                        for (int k = 1; k < 64;) {
+                            br.refill();
+                            const int rs = huff_symbol(br, look[2 * c + 1], lac, bad);
+                            const int r = rs >> 4, sz2 = rs & 15;
+                            if (sz2 == 0) {
+                                if (r == 15) { k += 16; continue; }
+                                break;                                      // EOB
+                            }
+                            k += r;
+                            int v = (int)br.peek(sz2); br.skip(sz2);
+                            if (v < (1 << (sz2 - 1))) v -= (1 << sz2) - 1;
+                            blk[kDecZigzag[k & 63]] = (int16_t)v;           // (k & 63: a corrupt run cannot leave the block)
+                            ++k;
+                        }
+                        if (br.pos > br.len + 8) bad = true;                // ran past the data: stop believing it
+                    }
+            }
+            if (bad) break;                                                 // (every loop above is bounded; a bad stream ends early)
+            if (++mx == im.mcux) { mx = 0; ++my; }
+        }
+    }
+    if (bad && status) atomicOr(status + blockIdx.x, 1);
+}
+
+// ---- jidctint.c jpeg_idct_islow, one dimension (CONST_BITS = 13) ---------------------------------------------------
+__device__ __forceinline__ void idct8(const int (&x)[8], int (&o)[8], int shift) {
+    constexpr int F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633,
+                  F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
+    int z2 = x[2], z3 = x[6];
+    int z1 = (z2 + z3) * F_0_541;
+    int tmp2 = z1 + z3 * (-F_1_847);
+    int tmp3 = z1 + z2 * F_0_765;
+    int tmp0 = (x[0] + x[4]) * 8192, tmp1 = (x[0] - x[4]) * 8192;            // << CONST_BITS (written as a multiply: no UB on negatives)
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = x[7]; tmp1 = x[5]; tmp2 = x[3]; tmp3 = x[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    int z4 = tmp1 + tmp3;
+    const int z5 = (z3 + z4) * F_1_175;
+    tmp0 *= F_0_298; tmp1 *= F_2_053; tmp2 *= F_3_072; tmp3 *= F_1_501;
+    z1 *= -F_0_899; z2 *= -F_2_562; z3 = z3 * (-F_1_961) + z5; z4 = z4 * (-F_0_390) + z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    const int rnd = 1 << (shift - 1);
+    o[0] = (tmp10 + tmp3 + rnd) >> shift; o[7] = (tmp10 - tmp3 + rnd) >> shift;
+    o[1] = (tmp11 + tmp2 + rnd) >> shift; o[6] = (tmp11 - tmp2 + rnd) >> shift;
+    o[2] = (tmp12 + tmp1 + rnd) >> shift; o[5] = (tmp12 - tmp1 + rnd) >> shift;
+    o[3] = (tmp13 + tmp0 + rnd) >> shift; o[4] = (tmp13 - tmp0 + rnd) >> shift;
+}
+
+// sample_range_limit + CENTERJSAMPLE indexed with (x & RANGE_MASK) (jdmaster.c prepare_range_limit_table)
+__device__ __forceinline__ u32 range_limit_centered(int x) {
+    const int i = x & 1023;
+    return (u32)(i < 128 ? i + 128 : (i < 512 ? 255 : (i < 896 ? 0 : i - 896)));
+}
+
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restrict__ coefs, const imgxf_jpeg_dec_image* __restrict__ images,
+                                                        const uint16_t* __restrict__ quants, u8* __restrict__ planes) {
+    __shared__ int ws[32][8][9];
+    const imgxf_jpeg_dec_image& im = images[blockIdx.y];
+    const int lb = threadIdx.x >> 3, t = threadIdx.x & 7;
+    int g = blockIdx.x * 32 + lb, c = 0;
+    bool live = false;
+    for (; c < im.ncomp; ++c) {
+        const int nb = im.comp[c].blocks_x * im.comp[c].blocks_y;
+        if (g < nb) { live = true; break; }
+        g -= nb;
+    }
+    const imgxf_jpeg_dec_comp& cp = im.comp[live ? c : 0];
+    if (live) {                                                             // pass 1: column t of block g
+        const int16_t* blk = coefs + cp.coef_off + (int64_t)g * 64;
+        const uint16_t* q = quants + cp.quant * 64;
+        int x[8], o[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = (int)blk[r * 8 + t] * (int)q[r * 8 + t];
+        idct8(x, o, 13 - 2);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ws[lb][r][t] = o[r];
+    }
+    __syncthreads();
+    if (live) {                                                             // pass 2: row t
+        int x[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = ws[lb][t][k];
+        idct8(x, o, 13 + 2 + 3);
+        const int by = g / cp.blocks_x, bx = g - by * cp.blocks_x;
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lo |= range_limit_centered(o[k]) << (8 * k); hi |= range_limit_centered(o[k + 4]) << (8 * k); }
+        uint2* dst = (uint2*)(planes + cp.plane_off + (int64_t)(by * 8 + t) * (cp.blocks_x * 8) + bx * 8);
+        *dst = make_uint2(lo, hi);                                          // (plane_off and the pitch are multiples of 8)
+    }
+}
+
+// chroma sample at full-resolution position (x, y): jdsample.c
+__device__ __forceinline__ int chroma_at(const u8* pl, const imgxf_jpeg_dec_comp& cp, int pitch, int hmax, int vmax, int x, int y) {
+    if (cp.h == hmax && cp.v == vmax) return pl[(int64_t)y * pitch + x];
+    const int i = x >> 1;
+    if (cp.v == vmax) {                                                     // h2v1_fancy_upsample
+        const u8* row = pl + (int64_t)y * pitch;
+        const int cur = row[i];
+        if (x & 1) return i == cp.dw - 1 ? cur : (3 * cur + row[i + 1] + 2) >> 2;
+        return i == 0 ? cur : (3 * cur + row[i - 1] + 1) >> 2;
+    }
+    // h2v2_fancy_upsample: the nearer row counts 3, the farther 1; rows beyond the component are its edge rows
+    const int r = y >> 1;
+    const int nr = (y & 1) ? min(r + 1, cp.dh - 1) : max(r - 1, 0);
+    const u8* r0 = pl + (int64_t)r * pitch;
+    const u8* r1 = pl + (int64_t)nr * pitch;
+    const int cs = 3 * r0[i] + r1[i];
+    if (x & 1) return i == cp.dw - 1 ? (cs * 4 + 7) >> 4 : (3 * cs + (3 * r0[i + 1] + r1[i + 1]) + 7) >> 4;
+    return i == 0 ? (cs * 4 + 8) >> 4 : (3 * cs + (3 * r0[i - 1] + r1[i - 1]) + 8) >> 4;
+}
+
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const u8* __restrict__ planes, const imgxf_jpeg_dec_image* __restrict__ images,
+                                                         u8* __restrict__ out) {
+    const imgxf_jpeg_dec_image& im = images[blockIdx.y];
+    const int gw = (im.width + 3) >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)gw * im.height) return;
+    const int y = (int)(idx / gw), x0 = (int)(idx - (int64_t)y * gw) * 4;
+    const int npx = min(4, im.width - x0);
+    const imgxf_jpeg_dec_comp& c0 = im.comp[0];
+    const u8* py = planes + c0.plane_off + (int64_t)y * (c0.blocks_x * 8) + x0;
+    u8 px[12];
+    if (im.ncomp == 1) {
+        for (int j = 0; j < npx; ++j) { px[3 * j] = py[j]; px[3 * j + 1] = py[j]; px[3 * j + 2] = py[j]; }
+    } else {
+        const imgxf_jpeg_dec_comp& c1 = im.comp[1];
+        const imgxf_jpeg_dec_comp& c2 = im.comp[2];
+        const u8* pb = planes + c1.plane_off;
+        const u8* pr = planes + c2.plane_off;
+        for (int j = 0; j < npx; ++j) {
+            const int yy = py[j];
+            const int cb = chroma_at(pb, c1, c1.blocks_x * 8, im.hmax, im.vmax, x0 + j, y) - 128;
+            const int cr = chroma_at(pr, c2, c2.blocks_x * 8, im.hmax, im.vmax, x0 + j, y) - 128;
+            // jdcolor.c build_ycc_rgb_table: FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
+            const int r = yy + ((91881 * cr + 32768) >> 16);
+            const int g = yy + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+            const int b = yy + ((116130 * cb + 32768) >> 16);
+            px[3 * j] = (u8)min(max(r, 0), 255); px[3 * j + 1] = (u8)min(max(g, 0), 255); px[3 * j + 2] = (u8)min(max(b, 0), 255);
+        }
+    }
+    u8* dst = out + im.out_off + (int64_t)y * im.out_pitch + (int64_t)x0 * 3;
+    if (npx == 4 && (((uintptr_t)dst) & 3) == 0) {
+        u32* d4 = (u32*)dst;
+        d4[0] = px[0] | (px[1] << 8) | (px[2] << 16) | ((u32)px[3] << 24);
+        d4[1] = px[4] | (px[5] << 8) | (px[6] << 16) | ((u32)px[7] << 24);
+        d4[2] = px[8] | (px[9] << 8) | (px[10] << 16) | ((u32)px[11] << 24);
+    } else {
+        for (int j = 0; j < 3 * npx; ++j) dst[j] = px[j];
+    }
+}
+
+static int dec_check_host(const imgxf_jpeg_dec_image* host, int n, int64_t* max_blocks, int64_t* max_quads) {
+    *max_blocks = 0; *max_quads = 0;
+    for (int i = 0; i < n; ++i) {
+        const imgxf_jpeg_dec_image& im = host[i];
+        if (im.ncomp != 1 && im.ncomp != 3) return IMGXF_ERR_UNSUPPORTED;
+        if (im.width < 1 || im.height < 1 || im.width > 65535 || im.height > 65535) return IMGXF_ERR_SHAPE;
+        int64_t nb = 0;
+        for (int c = 0; c < im.ncomp; ++c) {
+            const imgxf_jpeg_dec_comp& cp = im.comp[c];
+            if (cp.h < 1 || cp.h > 2 || cp.v < 1 || cp.v > 2 || cp.blocks_x < 1 || cp.blocks_y < 1) return IMGXF_ERR_UNSUPPORTED;
+            if ((cp.plane_off & 7) != 0) return IMGXF_ERR_ARG;
+            nb += (int64_t)cp.blocks_x * cp.blocks_y;
+        }
+        if (im.ncomp == 3) {
+            const imgxf_jpeg_dec_comp& a = im.comp[0];
+            if (a.h != im.hmax || a.v != im.vmax) return IMGXF_ERR_UNSUPPORTED;
+            for (int c = 1; c < 3; ++c) {
+                const imgxf_jpeg_dec_comp& cp = im.comp[c];
+                const bool full = cp.h == im.hmax && cp.v == im.vmax, h2v1 = cp.h * 2 == im.hmax && cp.v == im.vmax,
+                           h2v2 = cp.h * 2 == im.hmax && cp.v * 2 == im.vmax;
+                if (!(full || h2v1 || h2v2)) return IMGXF_ERR_UNSUPPORTED;
+            }
+        }
+        if (nb > *max_blocks) *max_blocks = nb;
+        const int64_t quads = (int64_t)((im.width + 3) >> 2) * im.height;
+        if (quads > *max_quads) *max_quads = quads;
+    }
+    return IMGXF_OK;
+}
+
+} // namespace imgxf
+
+using namespace imgxf;
+
+IMGXF_API int imgxf_jpeg_decode_huffman(const uint8_t* scan, const int64_t* seg_off, const int32_t* seg_len,
+                                        const imgxf_jpeg_dec_image* images, int n, const imgxf_jpeg_dec_lut* luts,
+                                        int16_t* coefs, int32_t* status, void* stream) {
+    if (n < 0) return IMGXF_ERR_ARG;
+    if (n == 0) return IMGXF_OK;
+    if (!scan || !seg_off || !seg_len || !images || !luts || !coefs) return IMGXF_ERR_NULL;
+    hipLaunchKernelGGL(jpeg_huff_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_jpeg_decode_idct(const int16_t* coefs, const imgxf_jpeg_dec_image* images, const imgxf_jpeg_dec_image* images_host,
+                                     int n, const uint16_t* quants, uint8_t* planes, void* stream) {
+    if (n < 0) return IMGXF_ERR_ARG;
+    if (n == 0) return IMGXF_OK;
+    if (!coefs || !images || !images_host || !quants || !planes) return IMGXF_ERR_NULL;
+    if (n > 65535) return IMGXF_ERR_SHAPE;
+    int64_t mb, mq;
+    IMGXF_CHECK(dec_check_host(images_host, n, &mb, &mq));
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((mb + 31) / 32), (unsigned)n), dim3(256), 0, (hipStream_t)stream, coefs, images, quants, planes);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_jpeg_decode_color(const uint8_t* planes, const imgxf_jpeg_dec_image* images, const imgxf_jpeg_dec_image* images_host,
+                                      int n, uint8_t* out, void* stream) {
+    if (n < 0) return IMGXF_ERR_ARG;
+    if (n == 0) return IMGXF_OK;
+    if (!planes || !images || !images_host || !out) return IMGXF_ERR_NULL;
+    if (n > 65535) return IMGXF_ERR_SHAPE;
+    int64_t mb, mq;
+    IMGXF_CHECK(dec_check_host(images_host, n, &mb, &mq));
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((mq + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, planes, images, out);
+    return launch_status();
+}

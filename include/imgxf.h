@@ -359,6 +359,50 @@ int imgxf_percentile_mask_u8(const imgxf_view* src, const uint32_t* hist, double
 int imgxf_dilate_cross_u8(const imgxf_view* src, const imgxf_view* dst, int iterations,
                           void* stream);
 
+/* ---- f-4 (decode half): Image.open(path).convert("RGB")  transformation.py:83 -----------------------
+ * Baseline / extended-sequential Huffman JPEG, 8 bit, 1 or 3 components (Y or YCbCr; 4:4:4, 4:2:2 h2v1, 4:2:0 h2v2),
+ * decoded the way Pillow's libjpeg-turbo does with its defaults: jpeg_idct_islow, fancy (triangle) upsampling, the
+ * 16-bit fixed-point YCbCr -> RGB tables, grayscale replicated — bit-identical pixels.  The HOST parses the markers,
+ * removes the byte stuffing, splits the scan at RSTn markers and derives the lookup tables (imagetransformations_amd/
+ * jpeg.py); the device does the entropy decoding (one thread per restart segment — a file without restart markers is one
+ * segment: Huffman decoding is the serial direction), dequantisation + IDCT, upsampling and colour conversion.
+ * All arrays are DEVICE pointers; offsets are in elements of the array they index. */
+typedef struct imgxf_jpeg_dec_comp {
+    int32_t h, v;               /* sampling factors (1 or 2) */
+    int32_t dc_tab, ac_tab;     /* indices into luts[] (imgxf_jpeg_dec_lut) */
+    int32_t quant;              /* index into quants[] (64 uint16 each, natural order) */
+    int32_t blocks_x, blocks_y; /* allocated blocks: mcux * h, mcuy * v */
+    int32_t dw, dh;             /* downsampled_width / height: ceil(width * h / hmax), ceil(height * v / vmax) */
+    int64_t coef_off;           /* first int16 coefficient of the component in coefs[] ([blocks_y][blocks_x][64], natural order) */
+    int64_t plane_off;          /* first byte of the component's sample plane in planes[] (pitch = 8 * blocks_x) */
+} imgxf_jpeg_dec_comp;
+typedef struct imgxf_jpeg_dec_image {
+    int32_t width, height, ncomp, hmax, vmax, mcux, mcuy;
+    int32_t restart_interval;   /* MCUs per segment (the whole scan when the file has no DRI) */
+    int32_t seg_first, seg_count; /* this image's entries of seg_off[] (byte offset of each segment in scan[]) and seg_len[] */
+    int32_t pad_;
+    int64_t out_off;            /* first byte of the image's RGB pixels in out[] (row pitch = out_pitch bytes) */
+    int64_t out_pitch;
+    imgxf_jpeg_dec_comp comp[3];
+} imgxf_jpeg_dec_image;
+typedef struct imgxf_jpeg_dec_lut {
+    uint16_t look[256];         /* 8-bit lookahead: (code length << 8) | symbol, 0 = the code is longer than 8 bits */
+    int32_t  maxcode[18];       /* jdhuff.c: largest code of each length (index 1..16), -1 if none; [17] = sentinel */
+    int32_t  valoff[17];        /* huffval index of the first code of each length minus that code */
+    uint8_t  huffval[256];
+} imgxf_jpeg_dec_lut;
+/* Entropy decoding of n images: coefs[] must be ZERO on entry (only non-zero coefficients are written).  status[i]
+ * (device int32, may be NULL) receives 0, or 1 when image i's stream held an impossible code / ran out of data. */
+int imgxf_jpeg_decode_huffman(const uint8_t* scan, const int64_t* seg_off, const int32_t* seg_len,
+                              const imgxf_jpeg_dec_image* images, int n, const imgxf_jpeg_dec_lut* luts,
+                              int16_t* coefs, int32_t* status, void* stream);
+/* Dequantisation + jpeg_idct_islow of every block of n images into their sample planes. */
+int imgxf_jpeg_decode_idct(const int16_t* coefs, const imgxf_jpeg_dec_image* images, const imgxf_jpeg_dec_image* images_host,
+                           int n, const uint16_t* quants, uint8_t* planes, void* stream);
+/* Fancy upsampling + YCbCr -> RGB (or gray -> RGB) of n images into out[] (HWC uint8 RGB at out_off / out_pitch). */
+int imgxf_jpeg_decode_color(const uint8_t* planes, const imgxf_jpeg_dec_image* images, const imgxf_jpeg_dec_image* images_host,
+                            int n, uint8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

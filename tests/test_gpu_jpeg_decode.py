@@ -1,0 +1,109 @@
+"""GPU: the device JPEG reader (csrc/jpeg_decode.hip + imagetransformations_amd/jpeg_decode.py) — the decode half of
+the reference's load step `Image.open(path).convert("RGB")` (/root/reference/transformation.py:83) — against Pillow /
+libjpeg-turbo itself and the NumPy oracle: bit-identical pixels on the 30 files the reference wrote
+(tests/golden/reference_outputs/) and on seeded images of every size class, sampling, quality and table kind."""
+import glob
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import synth
+from oracle import jpeg_decode_oracle as JD
+from test_jpeg_decode_oracle import photo_like, pillow_rgb
+
+pytestmark = pytest.mark.gpu
+REF = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "reference_outputs", "*.JPEG")))
+
+
+def jpeg_bytes(img, **kw):
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def test_reference_written_files_in_one_batch(device):
+    from imagetransformations_amd import jpeg_decode
+    files = [open(p, "rb").read() for p in REF]
+    assert len(files) == 30
+    frames = jpeg_decode.decode(files, device)
+    for p, data, t in zip(REF, files, frames):
+        want = pillow_rgb(data)
+        assert t.device.type == "cuda" and tuple(t.shape) == want.shape
+        assert np.array_equal(t.cpu().numpy(), want), os.path.basename(p)
+    assert np.array_equal(frames[3].cpu().numpy(), JD.decode(files[3]))
+
+
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+def test_sizes_samplings_qualities(device, subsampling):
+    from imagetransformations_amd import jpeg_decode
+    files, wants = [], []
+    for (h, w) in [(1, 1), (7, 5), (8, 8), (16, 16), (17, 33), (31, 15), (48, 64), (100, 75), (375, 500), (123, 457)]:
+        for seed, quality in ((1, 75), (2, 30), (3, 95)):
+            for img in (synth(seed * 7 + h, h, w), photo_like(seed, h, w)):
+                files.append(jpeg_bytes(img, quality=quality, subsampling=subsampling))
+                wants.append(pillow_rgb(files[-1]))
+    frames = jpeg_decode.decode(files, device)
+    for k, (t, want) in enumerate(zip(frames, wants)):
+        assert np.array_equal(t.cpu().numpy(), want), (k, want.shape)
+
+
+def test_grayscale_optimised_tables_restart_intervals_and_groups(device):
+    from imagetransformations_amd import jpeg_decode
+    img = photo_like(5, 161, 283)
+    files = [jpeg_bytes(img, optimize=True), jpeg_bytes(img, quality=10), jpeg_bytes(img, quality=100, subsampling=0),
+             jpeg_bytes(img, restart_marker_blocks=3), jpeg_bytes(img, restart_marker_rows=1, subsampling=2),
+             jpeg_bytes(img, restart_marker_blocks=1, subsampling=1)]
+    buf = io.BytesIO(); Image.fromarray(img).convert("L").save(buf, "JPEG", quality=80); files.append(buf.getvalue())
+    buf = io.BytesIO(); Image.fromarray(img).convert("L").save(buf, "JPEG", quality=50, optimize=True, restart_marker_rows=2); files.append(buf.getvalue())
+    frames = jpeg_decode.decode(files, device)
+    for k, (t, f) in enumerate(zip(frames, files)):
+        assert np.array_equal(t.cpu().numpy(), pillow_rgb(f)), k
+    # equal-sized files share one allocation: the frames are views of a [N, H, W, 3] batch
+    assert frames[0].untyped_storage().data_ptr() == frames[1].untyped_storage().data_ptr()
+    groups = jpeg_decode.decode_batches(files, device)
+    (batch, members), = groups.values()
+    assert tuple(batch.shape) == (len(files), 161, 283, 3) and members == list(range(len(files)))
+
+
+def test_full_hd_and_4k_frames(device):
+    from imagetransformations_amd import jpeg_decode
+    files = [jpeg_bytes(photo_like(9, 1080, 1920)), jpeg_bytes(photo_like(10, 2160, 3840), restart_marker_rows=1),
+             jpeg_bytes(synth(11, 540, 960), quality=90)]
+    frames = jpeg_decode.decode(files, device)
+    for t, f in zip(frames, files):
+        assert np.array_equal(t.cpu().numpy(), pillow_rgb(f))
+
+
+def test_unsupported_and_damaged_files(device):
+    from imagetransformations_amd import _ffi, jpeg_decode
+    img = photo_like(1, 64, 64)
+    with pytest.raises(jpeg_decode.UnsupportedJpeg):
+        jpeg_decode.decode([jpeg_bytes(img, progressive=True)], device)
+    buf = io.BytesIO(); Image.fromarray(img).convert("CMYK").save(buf, "JPEG")
+    with pytest.raises(jpeg_decode.UnsupportedJpeg):
+        jpeg_decode.decode([buf.getvalue()], device)
+    with pytest.raises(jpeg_decode.UnsupportedJpeg):
+        jpeg_decode.decode([b"not a jpeg at all"], device)
+    good = jpeg_bytes(img, optimize=True)
+    info = jpeg_decode.parse(good)
+    cut = good[:info["ecs"][0] + 40] + b"\xff\xd9"                      # the scan stops after 40 bytes
+    with pytest.raises(_ffi.ImgxfError):
+        jpeg_decode.decode([good, cut], device)
+    assert jpeg_decode.decode([], device) == []
+    with pytest.raises(_ffi.ImgxfError):
+        jpeg_decode.decode([good], "cpu")                                # there is no CPU fallback
+
+
+def test_decode_then_transform_stays_on_the_device(device):
+    """load -> transform without a host round trip: the reader's frames feed the ops directly."""
+    from imagetransformations_amd import jpeg_decode, ops
+    files = [open(p, "rb").read() for p in REF[:4]]
+    frames = jpeg_decode.decode(files, device)
+    for t, f in zip(frames, files):
+        from oracle import imgxf_oracle as O
+        a = pillow_rgb(f)
+        assert np.array_equal(ops.rotate(t, -22.5, ops.NEAREST, (0, 0, 0)).cpu().numpy(), O.apply_rotation(a, 22.5))
