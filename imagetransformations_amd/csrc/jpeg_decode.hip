@@ -24,19 +24,23 @@ __constant__ u8 kDecZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 
 typedef uint32_t u32_una __attribute__((aligned(1)));
 
 struct BitReader {
-    const u8* p;            // segment bytes (stuffing removed)
-    int len, pos;           // bytes, next byte to load
+    const u8* p;            // segment bytes (stuffing removed; the host pads every segment with >= 16 zero bytes)
+    int len, pos;           // bytes; position of `nextw`
     uint64_t acc;           // next bits, left aligned
     int nb;                 // valid bits in acc
+    u32 nextw;              // the four bytes at `pos`, already loaded: the load of the following word is issued when this
+                            // one is consumed, so its latency overlaps the decoding of ~6 symbols instead of stalling them
+    __device__ __forceinline__ u32 load(int at) const {
+        return __builtin_bswap32(*(const u32_una*)(p + min(at, len + 8)));      // (beyond the data: the zero padding)
+    }
+    __device__ __forceinline__ void start(const u8* ptr, int n) {
+        p = ptr; len = n; pos = 0; acc = 0; nb = 0; nextw = load(0);
+    }
     __device__ __forceinline__ void refill() {
-        // four bytes at a time while there is room; past the end of the segment zero bits are fed (jdhuff.c does the
-        // same after its "premature end of data" warning) — the caller notices through pos > len + 8
         while (nb <= 32) {
-            u32 w = 0;
-            if (pos + 4 <= len) w = __builtin_bswap32(*(const u32_una*)(p + pos));
-            else for (int i = 0; i < 4; ++i) w = (w << 8) | (pos + i < len ? p[pos + i] : 0u);
-            acc |= (uint64_t)w << (32 - nb);
+            acc |= (uint64_t)nextw << (32 - nb);
             nb += 32; pos += 4;
+            nextw = load(pos);
         }
     }
     __device__ __forceinline__ u32 peek(int n) const { return (u32)(acc >> (64 - n)); }
@@ -61,7 +65,12 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const u8* __restrict__ sc
                                                        const imgxf_jpeg_dec_lut* __restrict__ luts, int16_t* __restrict__ coefs,
                                                        int32_t* __restrict__ status) {
     __shared__ uint16_t look[6][256];
-    const imgxf_jpeg_dec_image& im = images[blockIdx.x];
+    __shared__ u8 zz[64];                          // the zigzag map and the image descriptor live in LDS: a __constant__ /
+    __shared__ imgxf_jpeg_dec_image im_s;          // global read per coefficient is a memory round trip on the one busy lane
+    zz[threadIdx.x] = kDecZigzag[threadIdx.x];
+    for (int i = threadIdx.x; i < (int)(sizeof(imgxf_jpeg_dec_image) / 4); i += 64) ((u32*)&im_s)[i] = ((const u32*)(images + blockIdx.x))[i];
+    __syncthreads();
+    const imgxf_jpeg_dec_image& im = im_s;
     for (int i = threadIdx.x; i < 6 * 256; i += 64) {
         const int slot = i >> 8, c = slot >> 1;
         if (c < im.ncomp) look[slot][i & 255] = luts[(slot & 1) ? im.comp[c].ac_tab : im.comp[c].dc_tab].look[i & 255];
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const u8* __restrict__ sc
     bool bad = false;
     for (int s = threadIdx.x; s < im.seg_count; s += 64) {
         BitReader br;
-        br.p = scan + seg_off[im.seg_first + s]; br.len = seg_len[im.seg_first + s]; br.pos = 0; br.acc = 0; br.nb = 0;
+        br.start(scan + seg_off[im.seg_first + s], seg_len[im.seg_first + s]);
         int pred[3] = {0, 0, 0};
         const int m0 = s * im.restart_interval, m1 = min(total, m0 + im.restart_interval);
         int my = m0 / im.mcux, mx = m0 - my * im.mcux;
@@ -103,10 +112,10 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const u8* __restrict__ sc
                             k += r;
                             int v = (int)br.peek(sz2); br.skip(sz2);
                             if (v < (1 << (sz2 - 1))) v -= (1 << sz2) - 1;
-                            blk[kDecZigzag[k & 63]] = (int16_t)v;           // (k & 63: a corrupt run cannot leave the block)
+                            blk[zz[k & 63]] = (int16_t)v;           // (k & 63: a corrupt run cannot leave the block)
                             ++k;
                         }
-                        if (br.pos > br.len + 8) bad = true;                // ran past the data: stop believing it
+                        if (br.pos > br.len + 16) bad = true;               // ran past the data: stop believing it
                     }
             }
             if (bad) break;                                                 // (every loop above is bounded; a bad stream ends early)

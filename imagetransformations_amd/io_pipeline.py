@@ -35,6 +35,48 @@ def _decode(path: str):
         return None
 
 
+def _read(path: str):
+    try:
+        with open(path, "rb") as f:
+            return f.read(), path
+    except Exception as e:
+        print(f"Failed to load image {path}: {e}")
+        return None
+
+
+DECODE_STATS = {"device": 0, "pillow": 0}      # files decoded by the device reader / handed to Pillow by decoder="device"
+
+
+def _decode_on_device(read):
+    """[(bytes, path)] -> [(frame, path)]: one `jpeg_decode.decode` over the chunk; a file outside the device reader's
+    class (progressive, CMYK, ...: `UnsupportedJpeg`) or one it finds damaged is decoded by Pillow, as :83 does, and
+    uploaded — counted in DECODE_STATS so that the share is visible."""
+    import io
+    import numpy as np
+    import torch
+    from . import jpeg_decode
+    from ._ffi import ImgxfError
+    items = [r for r in read if r is not None]
+    try:
+        frames = jpeg_decode.decode([d for d, _ in items])
+        DECODE_STATS["device"] += len(items)
+        return [(t, p) for t, (_, p) in zip(frames, items)]
+    except (jpeg_decode.UnsupportedJpeg, ImgxfError):
+        out = []
+        for d, p in items:
+            try:
+                out.append((jpeg_decode.decode([d])[0], p))
+                DECODE_STATS["device"] += 1
+            except (jpeg_decode.UnsupportedJpeg, ImgxfError):
+                try:
+                    img = Image.open(io.BytesIO(d)).convert("RGB")
+                    out.append((torch.from_numpy(np.asarray(img)).cuda(), p))
+                    DECODE_STATS["pillow"] += 1
+                except Exception as e:
+                    print(f"Failed to load image {p}: {e}")
+        return out
+
+
 def _chunks(seq: Sequence, n: int) -> Iterable[Sequence]:
     for i in range(0, len(seq), n):
         yield seq[i:i + n]
@@ -42,26 +84,33 @@ def _chunks(seq: Sequence, n: int) -> Iterable[Sequence]:
 
 def run_directory(data_path: str, out_dir: str, chunk_images: int = 256, workers: int = 8,
                   transform: Callable[[List[Tuple[Image.Image, str]]], List[Tuple[str, Image.Image]]] | None = None,
-                  encoder: str = "pillow") -> int:
+                  encoder: str = "pillow", decoder: str = "pillow") -> int:
     """load_data + apply_all_transformations + save over a directory, streamed.  `transform` maps a
     chunk [(image, path)] to [(file name, image)] in output order; default: the batched
-    eight-transformation driver.  Returns the number of files written."""
+    eight-transformation driver.  Returns the number of files written.  `decoder="device"`: worker threads only READ the
+    files; the chunk is decoded by the GPU reader (`jpeg_decode.decode`, pixels identical to Pillow's) and the frames
+    go to the batched driver without ever visiting the host."""
     device_driver = transform is None and encoder == "device"
     if transform is None:
         from .transformation import apply_all_transformations_batched_named as transform
         from .transformation import apply_all_transformations_batched_to_files as to_files
     if encoder not in ("pillow", "device"):
         raise ValueError("encoder must be 'pillow' or 'device'")
+    if decoder not in ("pillow", "device"):
+        raise ValueError("decoder must be 'pillow' or 'device'")
+    load = _read if decoder == "device" else _decode
     os.makedirs(out_dir, exist_ok=True)
     chunk_paths = list(_chunks(list_images(data_path), chunk_images))
     written = 0
     with ThreadPoolExecutor(max_workers=workers) as pool:
-        decoding = pool.map(_decode, chunk_paths[0]) if chunk_paths else None
+        decoding = pool.map(load, chunk_paths[0]) if chunk_paths else None
         saving = []
         for k in range(len(chunk_paths)):
             chunk = [d for d in decoding if d is not None]
-            if k + 1 < len(chunk_paths):                        # the next chunk decodes while this one is on the GPU
-                decoding = pool.map(_decode, chunk_paths[k + 1])
+            if k + 1 < len(chunk_paths):                        # the next chunk decodes (is read) while this one is on the GPU
+                decoding = pool.map(load, chunk_paths[k + 1])
+            if decoder == "device":
+                chunk = _decode_on_device(chunk)
             if device_driver:                                   # transforms + JPEG writer, nothing but the files comes back
                 for fut in saving:
                     fut.result()
@@ -69,6 +118,8 @@ def run_directory(data_path: str, out_dir: str, chunk_images: int = 256, workers
                 written += len(to_files(chunk, out_dir)) if chunk else 0
                 continue
             named = transform(chunk) if chunk else []
+            if decoder == "device":                             # (apply_blur's radius-0 pass-through hands a device frame back)
+                named = [(nm, Image.fromarray(im.cpu().numpy()) if hasattr(im, "cpu") else im) for nm, im in named]
             for fut in saving:                                  # chunk k-1 has been encoding meanwhile
                 fut.result()
             written += len(named)
@@ -105,7 +156,7 @@ def _save_on_device(named, out_dir: str, pool, saving: list):
             rest.append((name, img))
     for items in groups.values():
         batch = torch.from_numpy(np.stack([np.asarray(img) for _, img in items])).cuda(non_blocking=True)
-        for (name, _), data in zip(items, jpeg.encode(batch)):
+        for (name, _), data in zip(items, jpeg.encode_views(batch)):
             saving.append(pool.submit(_write, data, os.path.join(out_dir, name)))
     return rest
 

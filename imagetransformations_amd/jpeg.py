@@ -109,6 +109,12 @@ def encode_device(frames: torch.Tensor, quality: int = 75, capacity: int | None 
 
 def encode(frames: torch.Tensor, quality: int = 75, capacity: int | None = None) -> List[bytes]:
     """One JPEG file (`bytes`) per frame, equal to Pillow's `Image.fromarray(frame).save(fp, "JPEG", quality=quality)`."""
+    return [bytes(v) for v in encode_views(frames, quality, capacity)]
+
+
+def encode_views(frames: torch.Tensor, quality: int = 75, capacity: int | None = None) -> List[memoryview]:
+    """`encode` without the last host copy: one memoryview per file into the pinned staging block the single D2H filled
+    (valid until they are dropped; `f.write(view)` writes a file straight from it)."""
     n, h, w = frames.shape[0], frames.shape[1], frames.shape[2]
     files, sizes = encode_device(frames, quality, capacity)
     lens = sizes.cpu().tolist()
@@ -119,12 +125,17 @@ def encode(frames: torch.Tensor, quality: int = 75, capacity: int | None = None)
         lens = sizes.cpu().tolist()
         if any(v == 0xFFFFFFFF for v in lens):
             raise F.ImgxfError(F.ERR_WORKSPACE, "a JPEG stream exceeds 12 bytes per pixel", "jpeg.encode")
+    # the files leave the device as ONE copy of sum(sizes) bytes: a device-side gather of the n streams (one torch.cat
+    # kernel over views of exactly each file's length) into a packed buffer, then a single D2H into pinned memory.
+    # (Round 2 issued one exact-size copy per file: 16 copies of ~0.7 MB cost 3.6 ms against 0.63 ms of encoding.)
     starts = [0]
     for v in lens:
-        starts.append(starts[-1] + ((v + 63) & ~63))
+        starts.append(starts[-1] + v)
+    if starts[-1] == 0:
+        return [memoryview(b"")] * n
+    packed = torch.cat([files[i, :v] for i, v in enumerate(lens)])
     staged = torch.empty((starts[-1],), dtype=torch.uint8, pin_memory=True)   # torch caches pinned blocks across calls
-    for i, v in enumerate(lens):                                               # exact-size, contiguous DMA copies
-        staged[starts[i]:starts[i] + v].copy_(files[i, :v], non_blocking=True)
+    staged.copy_(packed, non_blocking=True)
     torch.cuda.current_stream(frames.device).synchronize()
-    host = staged.numpy()
-    return [host[starts[i]:starts[i] + lens[i]].tobytes() for i in range(n)]
+    host = memoryview(staged.numpy())                        # (keeps the pinned block alive)
+    return [host[starts[i]:starts[i + 1]] for i in range(n)]

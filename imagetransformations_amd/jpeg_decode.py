@@ -183,16 +183,21 @@ def _segments(raw: bytes):
     return out
 
 
-def decode(files: Sequence[bytes], device=None) -> List[torch.Tensor]:
+LAST_PROFILE: dict = {}        # filled by decode(..., profile=True): seconds per stage of the last call (it synchronises)
+
+
+def decode(files: Sequence[bytes], device=None, profile: bool = False) -> List[torch.Tensor]:
     """One [H, W, 3] uint8 RGB device tensor per file: the pixels of `Image.open(BytesIO(f)).convert("RGB")`.
     Files of equal size share one [N, H, W, 3] allocation (the views are its frames), which is what the batched drivers
     group by.  Raises UnsupportedJpeg for a file outside the reader's class, ImgxfError for a damaged stream."""
     device = torch.device("cuda") if device is None else torch.device(device)
     if device.type != "cuda":
         raise F.ImgxfError(F.ERR_NO_DEVICE, "the JPEG reader runs on the GPU (no CPU fallback)", "jpeg_decode.decode")
+    import time
     n = len(files)
     if n == 0:
         return []
+    t_start = time.perf_counter()
     infos = [parse(bytes(f)) for f in files]
     luts: List[DecLut] = []
     lut_index: dict = {}
@@ -267,7 +272,19 @@ def decode(files: Sequence[bytes], device=None) -> List[torch.Tensor]:
             images[i].out_pitch = w * 3
         spans.append((out_pos, len(members), h, w, members))
         out_pos += (len(members) * h * w * 3 + 15) & ~15
+    t_host = time.perf_counter()
+
+    def mark(name, t0):
+        if profile:
+            torch.cuda.synchronize(device)
+            LAST_PROFILE[name] = time.perf_counter() - t0
+            return time.perf_counter()
+        return t0
+
     with torch.cuda.device(device):
+        if profile:
+            LAST_PROFILE.clear()
+            LAST_PROFILE["host parse + tables"] = t_host - t_start
         stream = torch.cuda.current_stream(device).cuda_stream
         out = torch.empty((out_pos,), dtype=torch.uint8, device=device)
         scan_host = torch.frombuffer(bytearray(b"".join(seg_bytes)), dtype=torch.uint8)
@@ -281,11 +298,15 @@ def decode(files: Sequence[bytes], device=None) -> List[torch.Tensor]:
         coefs = torch.zeros((coef_pos,), dtype=torch.int16, device=device)
         planes = torch.empty((plane_pos,), dtype=torch.uint8, device=device)
         status = torch.zeros((n,), dtype=torch.int32, device=device)
+        t0 = mark("uploads + zero fill", t_host)
         F.call("imgxf_jpeg_decode_huffman", scan_d.data_ptr(), seg_off_d.data_ptr(), seg_len_d.data_ptr(), images_d.data_ptr(), n,
                luts_d.data_ptr(), coefs.data_ptr(), status.data_ptr(), stream)
+        t0 = mark("huffman kernel", t0)
         F.call("imgxf_jpeg_decode_idct", coefs.data_ptr(), images_d.data_ptr(), C.addressof(images), n, quants_d.data_ptr(),
                planes.data_ptr(), stream)
+        t0 = mark("idct kernel", t0)
         F.call("imgxf_jpeg_decode_color", planes.data_ptr(), images_d.data_ptr(), C.addressof(images), n, out.data_ptr(), stream)
+        t0 = mark("upsample + colour kernel", t0)
         bad = torch.nonzero(status).flatten().tolist()
     if bad:
         raise F.ImgxfError(F.ERR_ARG, f"damaged entropy-coded data in file(s) {bad}", "jpeg_decode.decode")

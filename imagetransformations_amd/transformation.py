@@ -331,7 +331,7 @@ def apply_all_transformations_batched_to_files(images, out_dir: str) -> List[str
     def sink(out: torch.Tensor, names: List[str]) -> None:
         on_device = [n.lower().endswith((".jpg", ".jpeg")) for n in names]
         if all(on_device) and out.dim() == 4 and out.shape[-1] == 3:
-            for name, data in zip(names, jpeg.encode(out)):
+            for name, data in zip(names, jpeg.encode_views(out)):
                 with open(os.path.join(out_dir, name), "wb") as f:
                     f.write(data)
         else:                                             # another format: Pillow writes it
@@ -341,9 +341,20 @@ def apply_all_transformations_batched_to_files(images, out_dir: str) -> List[str
 
     named = apply_all_transformations_batched_named(images, _sink=sink)
     for name, img in named:
-        if img is not None:                               # per-image path (not RGB) or apply_blur's radius-0 pass-through
+        if isinstance(img, torch.Tensor):                 # apply_blur's radius-0 pass-through of a device frame
+            sink(img[None], [name])
+        elif img is not None:                             # per-image path (not RGB) or apply_blur's radius-0 pass-through
             save_image(img, os.path.join(out_dir, name))
     return [name for name, _ in named]
+
+
+def _size_of(img):
+    """(width, height) of a PIL image or of an [H, W, 3] device frame (the device JPEG reader's output)."""
+    return (int(img.shape[1]), int(img.shape[0])) if isinstance(img, torch.Tensor) else img.size
+
+
+def _is_rgb(img) -> bool:
+    return (img.dim() == 3 and img.shape[-1] == 3 and img.dtype == torch.uint8) if isinstance(img, torch.Tensor) else img.mode == 'RGB'
 
 
 def _collect(item, results) -> int:
@@ -361,7 +372,8 @@ def apply_all_transformations_batched_named(images, _sink=None):
     transform type per image, `np.random` for the noise, in the reference's order), same file
     names, same outputs in the same order — but every image is uploaded once, and all images
     of one size that drew the same (type, value) go through ONE batched launch.  Images that
-    are not 8-bit RGB take the per-image path.  images: [(PIL image, path)].  `_sink(out, names)`, when given,
+    are not 8-bit RGB take the per-image path.  images: [(PIL image, path)] — or [(frame, path)] with [H, W, 3] uint8
+    DEVICE tensors as the device JPEG reader returns them (`jpeg_decode.decode`): those are never copied to the host.  `_sink(out, names)`, when given,
     consumes a group's result ON THE DEVICE ([B, H, W, 3] tensor + its file names) instead of it being copied back:
     those entries come back as (file name, None)."""
     dev = _device()
@@ -372,7 +384,7 @@ def apply_all_transformations_batched_named(images, _sink=None):
         plans.append(plan)
         for k, (transform_type, args, _) in enumerate(plan):
             if transform_type == 'gaussian_noise':      # same np.random stream as the per-image loop
-                w, h = img.size
+                w, h = _size_of(img)
                 if NOISE_RNG == "device":               # opt-in: one seed per image instead of h * w * 3 normals
                     noise[(i, k)] = _noise_seed()
                 else:
@@ -381,8 +393,8 @@ def apply_all_transformations_batched_named(images, _sink=None):
     results = [[None] * len(p) for p in plans]
     by_size = {}
     for i, (img, _) in enumerate(images):
-        if img.mode == 'RGB':
-            by_size.setdefault(img.size, []).append(i)
+        if _is_rgb(img):
+            by_size.setdefault(_size_of(img), []).append(i)
         else:                                           # rare: keep the reference's behaviour exactly
             for k, (transform_type, args, _) in enumerate(plans[i]):
                 if transform_type == 'gaussian_noise':
@@ -400,7 +412,11 @@ def apply_all_transformations_batched_named(images, _sink=None):
     }
     pending, queued = [], 0                             # (Download, entries): results still on their way back
     for size, members in by_size.items():
-        frames = staging.upload([np.asarray(images[i][0]) for i in members], dev)   # one pinned block, async H2D
+        if all(isinstance(images[i][0], torch.Tensor) for i in members):            # already on the device (JPEG reader)
+            frames = torch.stack([images[i][0] for i in members])
+        else:
+            frames = staging.upload([np.asarray(images[i][0].cpu() if isinstance(images[i][0], torch.Tensor) else images[i][0])
+                                     for i in members], dev)                        # one pinned block, async H2D
         groups = {}
         for row, i in enumerate(members):
             for k, (transform_type, args, _) in enumerate(plans[i]):

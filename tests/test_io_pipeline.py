@@ -77,6 +77,31 @@ def test_streamed_directory_equals_per_image_driver(device, tmp_path):
         assert np.array_equal(got, np.asarray(Image.open(_io.BytesIO(buf.getvalue())).convert("RGB"))), fname
 
 
+@pytest.mark.gpu
+def test_device_decoder_gives_the_same_files(device, tmp_path):
+    """decoder="device": the chunk is decoded by the GPU reader and never visits the host before the transforms; the
+    files written are those of the Pillow-decoder run, byte for byte, with either encoder (a progressive and a broken
+    file in the tree take the Pillow / skip path and are counted)."""
+    from imagetransformations_amd import io_pipeline as IO
+    src = str(tmp_path / "in")
+    _make_tree(src)
+    Image.fromarray(synth(77, 40, 56)).save(os.path.join(src, "n01", "prog.jpeg"), progressive=True, quality=80)
+    outs = {}
+    for name, kw in (("pp", dict()), ("dp", dict(decoder="device")), ("dd", dict(decoder="device", encoder="device")),
+                     ("pd", dict(encoder="device"))):
+        dst = str(tmp_path / name)
+        random.seed(9); np.random.seed(9)
+        IO.DECODE_STATS.update(device=0, pillow=0)
+        n = IO.run_directory(src, dst, chunk_images=5, workers=3, **kw)
+        assert n == 8 * 12
+        if "decoder" in kw:
+            assert IO.DECODE_STATS == {"device": 11, "pillow": 1}
+        outs[name] = {f: open(os.path.join(dst, f), "rb").read() for f in sorted(os.listdir(dst))}
+    assert outs["pp"].keys() == outs["dp"].keys() == outs["dd"].keys() == outs["pd"].keys()
+    for f in outs["pp"]:
+        assert outs["pp"][f] == outs["dp"][f] == outs["dd"][f] == outs["pd"][f], f
+
+
 def test_cifar_c_extraction(tmp_path):
     """transformation.py:20-71: five severity slices per (50000,32,32,3) file, other shapes skipped."""
     from imagetransformations_amd import io_pipeline as IO
