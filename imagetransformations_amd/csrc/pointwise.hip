@@ -590,6 +590,33 @@ IMGXF_API int imgxf_add_noise_u8(const imgxf_view* src, const imgxf_view* noise_
     return launch_status();
 }
 
+// 3 -> 3 channel permutations (cv2.cvtColor RGB2BGR / BGR2RGB, transformation.py:233,252) on 16-byte chunks: a thread
+// moves 16 pixels = 48 bytes as three uint4; inside every 12-byte group of 4 pixels output dword j collects its four
+// bytes from at most three input dwords with two v_perm_b32 (selectors built once per launch on the host).
+struct PermSel { u32 s1[3], s2[3]; };
+__global__ __launch_bounds__(256) void permute_rgb16_kernel(View s, View d, PermSel ps) {
+    const int chunks = (d.w * 3) / 48;                                      // host: row bytes % 48 == 0
+    const int64_t total = (int64_t)d.n * d.h * chunks;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(t % chunks);
+        const int64_t r = t / chunks;
+        const int y = (int)(r % d.h), f = (int)(r / d.h);
+        const uint4* sp = (const uint4*)(s.row(f, y) + 48 * ck);
+        uint4* dp = (uint4*)(d.row(f, y) + 48 * ck);
+        const uint4 i0 = sp[0], i1 = sp[1], i2 = sp[2];
+        const u32 in[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
+        u32 o[12];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u32 t1 = __builtin_amdgcn_perm(in[3 * g + 1], in[3 * g], ps.s1[j]);      // bytes that live in dwords 0 / 1 of the group
+                o[3 * g + j] = __builtin_amdgcn_perm(in[3 * g + 2], t1, ps.s2[j]);             // ... and those of dword 2
+            }
+        dp[0] = make_uint4(o[0], o[1], o[2], o[3]); dp[1] = make_uint4(o[4], o[5], o[6], o[7]); dp[2] = make_uint4(o[8], o[9], o[10], o[11]);
+    }
+}
+
 IMGXF_API int imgxf_permute_u8(const imgxf_view* src, const imgxf_view* dst, const int32_t* perm,
                                void* stream) {
     IMGXF_CHECK(check_view(src));
@@ -603,6 +630,28 @@ IMGXF_API int imgxf_permute_u8(const imgxf_view* src, const imgxf_view* dst, con
     }
     if (empty_view(dst)) return IMGXF_OK;
     const View d = make_view(dst);
+    {
+        const View sv = make_view(src);
+        auto al16 = [](const View& v) { return ((((uintptr_t)v.p) | (uintptr_t)v.rs | (uintptr_t)v.fs) & 15) == 0; };
+        if (src->c == 3 && dst->c == 3 && (d.w * 3) % 48 == 0 && al16(sv) && al16(d) && !knob_set(K_NO_FAST_LEFTOVERS)) {
+            // output byte 4 j + e of a 12-byte group comes from input byte q = 3 ((4 j + e) / 3) + perm[(4 j + e) % 3] of the
+            // group's three dwords: t1 = perm(dword 1, dword 0) gathers the bytes that live there, perm(dword 2, t1) the rest
+            PermSel ps; memset(&ps, 0, sizeof(ps));
+            for (int j = 0; j < 3; ++j) {
+                u32 s1 = 0, s2 = 0;
+                for (int e = 0; e < 4; ++e) {
+                    const int ob = 4 * j + e, q = 3 * (ob / 3) + pm.v[ob % 3], dw = q >> 2, by = q & 3;
+                    const u32 sel1 = dw == 0 ? (u32)by : (dw == 1 ? (u32)(4 + by) : 0x0cu);       // 0x0c: constant zero
+                    const u32 sel2 = dw == 2 ? (u32)(4 + by) : (u32)e;                           // byte `by` of dword 2, else keep t1's byte e
+                    s1 |= sel1 << (8 * e); s2 |= sel2 << (8 * e);
+                }
+                ps.s1[j] = s1; ps.s2[j] = s2;
+            }
+            hipLaunchKernelGGL(permute_rgb16_kernel, dim3(grid_for((int64_t)d.n * d.h * ((d.w * 3) / 48))), dim3(256), 0,
+                               (hipStream_t)stream, sv, d, ps);
+            return launch_status();
+        }
+    }
     hipLaunchKernelGGL(permute_kernel, dim3(grid_for((int64_t)d.n * d.h * d.w)), dim3(256), 0,
                        (hipStream_t)stream, make_view(src), d, pm);
     return launch_status();
