@@ -507,8 +507,8 @@ def main():
     value = world * px_per_step * args.steps / elapsed / 1e6
 
     gauss = kernel_entry("sepconv_march (5x5 Gaussian, 4K RGB)", GAUSS_BYTES_PER_PX, px_per_step, g_ms, pmc_traffic("sepconv", F))
-    affine = kernel_entry("affine_bilinear_mf (rotate 30deg + 1.5x bilinear, 4K RGB)", AFFINE_BYTES_PER_PX, px_per_step, r_ms,
-                          pmc_traffic("affine_bilinear_mf", F))
+    affine = kernel_entry("affine_bilinear_wq (rotate 30deg + 1.5x bilinear, 4K RGB)", AFFINE_BYTES_PER_PX, px_per_step, r_ms,
+                          pmc_traffic("affine_bilinear", F))
     result = {
         "metric": METRIC,
         "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -535,7 +535,7 @@ def main():
         el, g2, r2, keep = timed_step(HHD, WHD, FH, args, rank, world, dist, dev, backend, precise)
         pxh = FH * HHD * WHD
         gh = kernel_entry("sepconv_march (5x5 Gaussian, 1080p RGB)", GAUSS_BYTES_PER_PX, pxh, g2, None)
-        ah = kernel_entry("affine_bilinear_mf (rotate 30deg + 1.5x bilinear, 1080p RGB)", AFFINE_BYTES_PER_PX, pxh, r2, None)
+        ah = kernel_entry("affine_bilinear_wq (rotate 30deg + 1.5x bilinear, 1080p RGB)", AFFINE_BYTES_PER_PX, pxh, r2, None)
         result["roofline_kernels"]["gaussian5x5_1080p"] = gh
         result["roofline_kernels"]["rotate30_zoom1.5_bilinear_1080p"] = ah
         resolutions["1920x1080"] = {"value": round(world * pxh * args.steps / el / 1e6, 1), "unit": "Mpix/s",

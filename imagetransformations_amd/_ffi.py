@@ -115,6 +115,10 @@ class JpegTables(C.Structure):
 
 
 def _load() -> C.CDLL:
+    # torch first: its wheel bundles the HIP runtime (libamdhip64) the process must share.  Loaded the other way round,
+    # libimgxf.so binds /opt/rocm's copy, torch then brings its own, and this library's launches fail with
+    # hipErrorNoDevice (seen with `python __graft_entry__.py --smoke`, where build() imports the package before torch).
+    import torch  # noqa: F401
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run "

@@ -27,6 +27,12 @@ FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-fvisibility=h
          "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
+# per-file additions.  affine.hip: hipcc's SLP vectoriser turns the bilinear kernels' 96 scalar v_fmac_f32 per 8 pixels into
+# 48 v_pk_fma_f32 across neighbouring pixels — fewer instructions, but a packed FMA issues in 4.5 cycles against 2.8 for a
+# scalar one, and the batch kernels measured 2 - 6 % SLOWER with it (profiles/r03_experiments/ab_affine_slp.txt)
+FILE_FLAGS = {"affine.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -45,9 +51,10 @@ def build_library(force: bool = False, verbose: bool = True, jobs: int | None = 
     sources = sorted(CSRC.glob("*.hip"))
     hdr_time = _newest_header()
     stamp = OBJ / "flags.txt"
-    if not stamp.exists() or stamp.read_text() != " ".join(FLAGS):
+    flag_text = " ".join(FLAGS) + " | " + repr(sorted(FILE_FLAGS.items()))
+    if not stamp.exists() or stamp.read_text() != flag_text:
         force = True
-        stamp.write_text(" ".join(FLAGS))
+        stamp.write_text(flag_text)
     todo = []
     objs = []
     for src in sources:
@@ -58,7 +65,7 @@ def build_library(force: bool = False, verbose: bool = True, jobs: int | None = 
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src.name}:\n{res.stdout}\n{res.stderr}")
