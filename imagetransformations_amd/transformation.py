@@ -133,7 +133,10 @@ def _blur_ksize(blur_radius: float) -> int:
     return ksize
 
 
-BLUR_FIXED_POINT = False     # True: evaluate cv2.GaussianBlur the way OpenCV's uint8 fixed-point path does
+# False (default): cv2.GaussianBlur by its float definition, the <= 1e-5 contract of BASELINE.json.  True (or
+# IMGXF_BLUR_FIXED_POINT=1): OpenCV's uint8 fixed-point evaluation (restated, unpinned), which the reference's own output
+# files sit marginally closer to (README.md)
+BLUR_FIXED_POINT = os.environ.get("IMGXF_BLUR_FIXED_POINT", "0") == "1"
 
 
 def apply_blur(img: Image.Image, blur_radius: float) -> Image.Image:
