@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-1080p", action="store_true")
+    ap.add_argument("--only-1080p", action="store_true",
+                    help="PMC passes: run only the 1920x1080 step (4x as many frames) and print a minimal line")
     ap.add_argument("--no-scatter-gather", action="store_true",
                     help="N > 1: skip the separate root<->ranks scatter + gather measurement")
     ap.add_argument("--scatter-gather", action="store_true", help="(default for N > 1; kept for compatibility)")
@@ -181,7 +183,7 @@ def in_kernel_sclk(dev, work, ms: float = 20.0):
             "how": "d s_memtime / d s_memrealtime x 100 MHz, one wave on a side stream under the step's kernels"}
 
 
-def pmc_traffic(kernel_key: str, frames: int):
+def pmc_traffic(kernel_key: str, frames: int, section: str = "kernels"):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic_pmc.json,
     written by tools/collect_traffic.py on the GPU box with the same frame count), corrected as
     MI355X_MICROARCH.md prescribes: FETCH_SIZE counts half the bytes of a wide coalesced stream on
@@ -191,7 +193,7 @@ def pmc_traffic(kernel_key: str, frames: int):
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
             if rec.get("frames_per_gpu") != frames:
                 continue
-            k = rec.get("kernels", {}).get(kernel_key) if "kernels" in rec else (rec if kernel_key == "sepconv" else None)
+            k = rec.get(section, {}).get(kernel_key) if "kernels" in rec else (rec if kernel_key == "sepconv" else None)
             if k:
                 return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0
         except Exception:
@@ -370,6 +372,31 @@ def ops_extras(F: int, dev, sclk_kernel):
     except Exception:
         pass
     extras["jpeg_save_q75_4k"] = rec
+    # the load step (transformation.py:83) on the device: 256 photograph-like 375 x 500 files (the reference's ImageNet size,
+    # written by the device writer = the files Pillow would write) -> RGB frames; host parsing and the upload of the
+    # compressed bytes are inside the time.  The entropy stage is latency bound (one lane per file: DESIGN 3.8)
+    try:
+        from imagetransformations_amd import jpeg_decode
+        yy = torch.arange(375, device=dev)[None, :, None, None].float(); xx = torch.arange(500, device=dev)[None, None, :, None].float()
+        ph = torch.arange(256, device=dev)[:, None, None, None].float(); ch = torch.arange(3, device=dev)[None, None, None, :].float()
+        small = (128 + 60 * torch.sin(xx / (17 + ch) + ph) + 50 * torch.cos(yy / 29 + 0.3 * ph) +
+                 6 * torch.randn((256, 375, 500, 3), device=dev, generator=gen)).clamp(0, 255).to(torch.uint8)
+        files = jpeg.encode(small)
+        jpeg_decode.decode(files[:8], dev)
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            frames = jpeg_decode.decode(files, dev)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        jpeg_decode.decode(files, dev, profile=True)
+        t = sorted(ts)[1]
+        extras["jpeg_load_375x500"] = {"files/s": round(256 / t, 1), "Mpix/s": round(256 * 375 * 500 / t / 1e6, 1), "files": 256,
+                                       "ms": round(t * 1e3, 2), "file_bytes_per_px": round(sum(len(f) for f in files) / (256 * 375 * 500), 3),
+                                       "stages_ms": {k: round(v * 1e3, 2) for k, v in jpeg_decode.LAST_PROFILE.items()},
+                                       "bound": "latency of the serial Huffman stage (one lane per restart segment)"}
+        del small, frames
+    except Exception as exc:                                # noqa: BLE001
+        extras["jpeg_load_375x500"] = {"error": repr(exc)[:200]}
     del sub, sub16, out, gray
     torch.cuda.empty_cache()
     return extras
@@ -497,6 +524,13 @@ def main():
 
     F = args.frames
     precise = not args.fast_bilinear
+    if args.only_1080p:                                      # (tools/profile_round.sh: FETCH_SIZE / WRITE_SIZE passes at 1080p)
+        el, g2, r2, keep = timed_step(HHD, WHD, 4 * F, args, rank, world, dist, dev, backend, precise)
+        if rank == 0:
+            print(json.dumps({"only": "1920x1080", "frames_per_gpu": 4 * F, "ms_per_step": round(el / args.steps * 1e3, 4)}))
+        if dist:
+            dist.barrier(); dist.destroy_process_group()
+        return
     sampler = SclkSampler(local)
     sampler.start()
     elapsed, g_ms, r_ms, keep = timed_step(H4K, W4K, F, args, rank, world, dist, dev, backend, precise)
@@ -534,8 +568,9 @@ def main():
         FH = 4 * F                                           # same bytes per GPU as the 4K batch
         el, g2, r2, keep = timed_step(HHD, WHD, FH, args, rank, world, dist, dev, backend, precise)
         pxh = FH * HHD * WHD
-        gh = kernel_entry("sepconv_march (5x5 Gaussian, 1080p RGB)", GAUSS_BYTES_PER_PX, pxh, g2, None)
-        ah = kernel_entry("affine_bilinear_wq (rotate 30deg + 1.5x bilinear, 1080p RGB)", AFFINE_BYTES_PER_PX, pxh, r2, None)
+        gh = kernel_entry("sepconv_march (5x5 Gaussian, 1080p RGB)", GAUSS_BYTES_PER_PX, pxh, g2, pmc_traffic("sepconv", F, "kernels_1080p"))
+        ah = kernel_entry("affine_bilinear_wq (rotate 30deg + 1.5x bilinear, 1080p RGB)", AFFINE_BYTES_PER_PX, pxh, r2,
+                          pmc_traffic("affine_bilinear", F, "kernels_1080p"))
         result["roofline_kernels"]["gaussian5x5_1080p"] = gh
         result["roofline_kernels"]["rotate30_zoom1.5_bilinear_1080p"] = ah
         resolutions["1920x1080"] = {"value": round(world * pxh * args.steps / el / 1e6, 1), "unit": "Mpix/s",

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void box_pass_kernel(View s, View d, int radiu
 //   horizontal: the lane's window (16 + 2 C (r+1) bytes, three aligned 16-byte loads) is unpacked once and the
 //               window sums of outputs i, i+C, i+2C ... follow each other by one add and one subtract.
 // Same integers as box_pass_kernel: out = (acc * ww + far * fw + 2^23) >> 24 in uint32.
-constexpr int BOX_RMAX = 4;
+constexpr int BOX_RMAX = 10;    // round 3: up to the radii of TransformationPool.defocus_blur (GaussianBlur radius 10 -> boxes of radius 8)
 
 __global__ __launch_bounds__(256) void box_v16_kernel(View s, View d, int radius, u32 ww, u32 fw) {
     const int nch = (int)(s.rowbytes() >> 4);
@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256) void box_v16_kernel(View s, View d, int radius
 
 template <int C, int R>
 __global__ __launch_bounds__(256) void box_h16_kernel(View s, View d, u32 ww, u32 fw) {
-    constexpr int HALO = C * (R + 1);                        // <= 16 (host)
+    constexpr int HALO = C * (R + 1);                        // bytes of window on either side of the lane's 16
+    constexpr int NB = (HALO + 15) / 16;                     // 16-byte blocks on either side (1 for the radii of round 2, up to 3)
     const int rowbytes = s.w * C;
     const int nch = (rowbytes + 15) >> 4;
     const int64_t total = (int64_t)s.n * s.h * nch;
@@ -286,13 +287,17 @@ __global__ __launch_bounds__(256) void box_h16_kernel(View s, View d, u32 ww, u3
         const int b0 = ck << 4;
         const u8* rp = s.row(f, y);
         u8* dp = d.row(f, y);
-        if (ck > 0 && b0 + 32 <= rowbytes) {                 // the three 16-byte blocks around b0 lie inside the row
-            const uint4 vl = *(const uint4*)(rp + b0 - 16), vc = *(const uint4*)(rp + b0), vr = *(const uint4*)(rp + b0 + 16);
-            const u32 src[12] = {vl.x, vl.y, vl.z, vl.w, vc.x, vc.y, vc.z, vc.w, vr.x, vr.y, vr.z, vr.w};
+        if (ck >= NB && b0 + 16 * (NB + 1) <= rowbytes) {    // the 2 NB + 1 blocks around b0 lie inside the row
+            u32 src[4 * (2 * NB + 1)];
+#pragma unroll
+            for (int q = 0; q < 2 * NB + 1; ++q) {
+                const uint4 v = *(const uint4*)(rp + b0 + 16 * (q - NB));
+                src[4 * q] = v.x; src[4 * q + 1] = v.y; src[4 * q + 2] = v.z; src[4 * q + 3] = v.w;
+            }
             u32 w[16 + 2 * HALO];                            // w[j] = byte b0 - HALO + j
 #pragma unroll
             for (int j = 0; j < 16 + 2 * HALO; ++j) {
-                const int p = 16 - HALO + j;
+                const int p = 16 * NB - HALO + j;
                 w[j] = (src[p >> 2] >> (8 * (p & 3))) & 0xffu;
             }
             u32 o[4] = {0u, 0u, 0u, 0u};
@@ -328,12 +333,11 @@ __global__ __launch_bounds__(256) void box_h16_kernel(View s, View d, u32 ww, u3
 
 template <int C>
 static bool launch_box_h16(const View& s, const View& d, int radius, u32 ww, u32 fw, unsigned blocks, hipStream_t st) {
+    if ((int64_t)s.rowbytes() < 16 * (2 * ((C * (radius + 1) + 15) / 16) + 1)) return false;    // no lane would take the wide path
     switch (radius) {
-        case 0: hipLaunchKernelGGL((box_h16_kernel<C, 0>), dim3(blocks), dim3(256), 0, st, s, d, ww, fw); return true;
-        case 1: hipLaunchKernelGGL((box_h16_kernel<C, 1>), dim3(blocks), dim3(256), 0, st, s, d, ww, fw); return true;
-        case 2: hipLaunchKernelGGL((box_h16_kernel<C, 2>), dim3(blocks), dim3(256), 0, st, s, d, ww, fw); return true;
-        case 3: hipLaunchKernelGGL((box_h16_kernel<C, 3>), dim3(blocks), dim3(256), 0, st, s, d, ww, fw); return true;
-        case 4: if (C * 5 <= 16) { hipLaunchKernelGGL((box_h16_kernel<C, (C * 5 <= 16 ? 4 : 0)>), dim3(blocks), dim3(256), 0, st, s, d, ww, fw); return true; } return false;
+#define IMGXF_BH(r) case r: hipLaunchKernelGGL((box_h16_kernel<C, r>), dim3(blocks), dim3(256), 0, st, s, d, ww, fw); return true;
+        IMGXF_BH(0) IMGXF_BH(1) IMGXF_BH(2) IMGXF_BH(3) IMGXF_BH(4) IMGXF_BH(5) IMGXF_BH(6) IMGXF_BH(7) IMGXF_BH(8) IMGXF_BH(9) IMGXF_BH(10)
+#undef IMGXF_BH
         default: return false;
     }
 }
@@ -399,7 +403,7 @@ IMGXF_API int imgxf_box_blur_u8(const imgxf_view* src, const imgxf_view* dst, fl
                 if (axis == 1) { hipLaunchKernelGGL(box_v16_kernel, dim3(b16), dim3(256), 0, st, cur, out, radius, ww, fw); launched = true; }
                 else if (s.c == 1) launched = launch_box_h16<1>(cur, out, radius, ww, fw, b16, st);
                 else if (s.c == 3) launched = launch_box_h16<3>(cur, out, radius, ww, fw, b16, st);
-                else if (s.c == 4 && radius <= 3) launched = launch_box_h16<4>(cur, out, radius, ww, fw, b16, st);
+                else if (s.c == 4) launched = launch_box_h16<4>(cur, out, radius, ww, fw, b16, st);
             }
             if (!launched)
                 hipLaunchKernelGGL(box_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur, out, radius, ww, fw, axis);

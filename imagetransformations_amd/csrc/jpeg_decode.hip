@@ -197,6 +197,8 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restric
 __device__ __forceinline__ int chroma_at(const u8* pl, const imgxf_jpeg_dec_comp& cp, int pitch, int hmax, int vmax, int x, int y) {
     if (cp.h == hmax && cp.v == vmax) return pl[(int64_t)y * pitch + x];
     const int i = x >> 1;
+    // jinit_upsampler: the fancy (triangle) filters only for downsampled_width > 2; narrower components are replicated
+    if (cp.dw <= 2) return pl[(int64_t)(cp.v == vmax ? y : y >> 1) * pitch + i];
     if (cp.v == vmax) {                                                     // h2v1_fancy_upsample
         const u8* row = pl + (int64_t)y * pitch;
         const int cur = row[i];

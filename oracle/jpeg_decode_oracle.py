@@ -248,12 +248,9 @@ def _plane(blocks):
 
 
 def _h2v1_fancy(p, dw):
-    """jdsample.c h2v1_fancy_upsample on rows of a plane whose real width is dw -> 2 dw columns."""
+    """jdsample.c h2v1_fancy_upsample on rows of a plane whose real width is dw (> 2) -> 2 dw columns."""
     p = p[:, :dw].astype(np.int64)
     out = np.empty((p.shape[0], 2 * dw), np.int64)
-    if dw == 1:
-        out[:, 0] = p[:, 0]; out[:, 1] = p[:, 0]
-        return out
     left = np.concatenate([p[:, :1], p[:, :-1]], axis=1)
     right = np.concatenate([p[:, 1:], p[:, -1:]], axis=1)
     out[:, 0::2] = (3 * p + left + 1) >> 2
@@ -272,10 +269,6 @@ def _h2v2_fancy(p, dw, dh):
     out = np.empty((2 * dh, 2 * dw), np.int64)
     for v, near in ((0, above), (1, below)):
         colsum = 3 * p + near                           # thiscolsum for every column
-        if dw == 1:
-            out[v::2, 0] = (colsum[:, 0] * 4 + 8) >> 4
-            out[v::2, 1] = (colsum[:, 0] * 4 + 7) >> 4
-            continue
         last = np.concatenate([colsum[:, :1], colsum[:, :-1]], axis=1)
         nxt = np.concatenate([colsum[:, 1:], colsum[:, -1:]], axis=1)
         even = (3 * colsum + last + 8) >> 4
@@ -309,9 +302,11 @@ def decode(data: bytes) -> np.ndarray:
         if ch == hmax and cv == vmax:
             up = p.astype(np.int64)
         elif ch * 2 == hmax and cv == vmax:
-            up = _h2v1_fancy(p[:dh], dw)
+            # jdsample.c jinit_upsampler: the fancy (triangle) filters are chosen only when downsampled_width > 2,
+            # narrower components are replicated (h2v1_upsample / h2v2_upsample)
+            up = _h2v1_fancy(p[:dh], dw) if dw > 2 else np.repeat(p[:dh, :dw].astype(np.int64), 2, axis=1)
         elif ch * 2 == hmax and cv * 2 == vmax:
-            up = _h2v2_fancy(p, dw, dh)
+            up = _h2v2_fancy(p, dw, dh) if dw > 2 else np.repeat(np.repeat(p[:dh, :dw].astype(np.int64), 2, axis=0), 2, axis=1)
         else:
             raise Unsupported("sampling %dx%d of %dx%d" % (ch, cv, hmax, vmax))
         full.append(up[:h, :w])

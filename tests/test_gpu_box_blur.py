@@ -18,9 +18,9 @@ def test_gaussian_and_box_blur_against_pillow(device, hw):
     a = synth(500, *hw)
     t = torch.from_numpy(a).to(device)
     img = Image.fromarray(a)
-    for radius in (0.5, 1, 2, 2.5, 3, 4, 5, 7.3):
+    for radius in (0.5, 1, 2, 2.5, 3, 4, 5, 6, 7.3, 8, 10, 12.5):        # 3, 4, 6, 8, 10: the five defocus_blur severities
         assert np.array_equal(ops.gaussian_blur_pil(t, radius).cpu().numpy(), np.asarray(img.filter(ImageFilter.GaussianBlur(radius)))), radius
-    for radius in (0.3, 1, 1.7, 2, 3.2, 4, 4.9, 6):
+    for radius in (0.3, 1, 1.7, 2, 3.2, 4, 4.9, 6, 7.5, 9, 10.9, 11.2):
         assert np.array_equal(ops.box_blur(t, radius).cpu().numpy(), np.asarray(img.filter(ImageFilter.BoxBlur(radius)))), radius
 
 
@@ -31,7 +31,7 @@ def test_wide_lane_passes_equal_per_byte_kernel(device, monkeypatch, c):
     a = rng.integers(0, 256, (3, 70, 208, c), dtype=np.uint8)
     a[0, :20] = 255; a[1, :, 50:90] = 0
     t = torch.from_numpy(a).to(device)
-    for radius in (0.4, 1.0, 2.6, 3.0, 4.5, 5.2):
+    for radius in (0.4, 1.0, 2.6, 3.0, 4.5, 5.2, 6.8, 8.0, 9.9, 10.5, 12.0):
         for passes in (1, 3):
             fast = ops.box_blur(t, radius, passes)
             monkeypatch.setenv("IMGXF_BOX_BYTES", "1")

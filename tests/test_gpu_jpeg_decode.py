@@ -41,7 +41,8 @@ def test_reference_written_files_in_one_batch(device):
 def test_sizes_samplings_qualities(device, subsampling):
     from imagetransformations_amd import jpeg_decode
     files, wants = [], []
-    for (h, w) in [(1, 1), (7, 5), (8, 8), (16, 16), (17, 33), (31, 15), (48, 64), (100, 75), (375, 500), (123, 457)]:
+    for (h, w) in [(1, 1), (7, 5), (8, 8), (16, 16), (17, 33), (31, 15), (48, 64), (100, 75), (375, 500), (123, 457),
+                   (9, 2), (40, 3), (174, 4), (21, 6), (2, 40)]:                # narrow files: libjpeg replicates chroma when its width <= 2
         for seed, quality in ((1, 75), (2, 30), (3, 95)):
             for img in (synth(seed * 7 + h, h, w), photo_like(seed, h, w)):
                 files.append(jpeg_bytes(img, quality=quality, subsampling=subsampling))

@@ -188,3 +188,41 @@ def test_soak_jpeg_writer_equals_pillow(device, seed):
         buf = io.BytesIO()
         Image.fromarray(a[i]).save(buf, "JPEG", quality=quality)
         assert files[i] == buf.getvalue(), (seed, i, a.shape, quality)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_soak_jpeg_reader_equals_pillow(device, seed):
+    """Round 3: the device JPEG reader on random files — sizes 1 … 300, gray / 4:4:4 / 4:2:2 / 4:2:0, qualities 1 … 100,
+    standard or optimised tables, with or without restart intervals, several files (equal and different sizes) per batch —
+    against Pillow's decoder, bit for bit."""
+    import io
+    from imagetransformations_amd import jpeg_decode
+    rng = np.random.default_rng(990000 + seed)
+    files = []
+    for _ in range(int(rng.integers(1, 6))):
+        h, w = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        if files and rng.random() < 0.3:
+            h, w = prev
+        prev = (h, w)
+        a = _img(rng, h, w)
+        kw = dict(quality=int(rng.integers(1, 101)))
+        gray = rng.random() < 0.2
+        if not gray:
+            kw["subsampling"] = int(rng.integers(0, 3))
+        if rng.random() < 0.3:
+            kw["optimize"] = True
+        r = rng.random()
+        if r < 0.2:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 9))
+        elif r < 0.4:
+            kw["restart_marker_rows"] = int(rng.integers(1, 4))
+        buf = io.BytesIO()
+        try:
+            (Image.fromarray(a).convert("L") if gray else Image.fromarray(a)).save(buf, "JPEG", **kw)
+        except OSError:          # Pillow's ENCODER gives up on some optimise + restart combinations ("Suspension not allowed here")
+            continue
+        files.append(buf.getvalue())
+    frames = jpeg_decode.decode(files, device)
+    for k, (t, f) in enumerate(zip(frames, files)):
+        want = np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))
+        assert np.array_equal(t.cpu().numpy(), want), (seed, k, want.shape)

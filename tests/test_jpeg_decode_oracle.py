@@ -34,7 +34,8 @@ def test_reference_written_files(path):
     assert np.array_equal(JD.decode(data), pillow_rgb(data))
 
 
-@pytest.mark.parametrize("h,w", [(1, 1), (7, 5), (8, 8), (16, 16), (17, 33), (31, 15), (48, 64), (100, 75)])
+@pytest.mark.parametrize("h,w", [(1, 1), (7, 5), (8, 8), (16, 16), (17, 33), (31, 15), (48, 64), (100, 75),
+                                 (9, 2), (40, 3), (174, 4), (21, 6), (2, 40)])    # widths <= 4: chroma narrower than 3 samples is replicated
 @pytest.mark.parametrize("subsampling", [0, 1, 2])                      # 4:4:4, 4:2:2, 4:2:0
 def test_sizes_and_samplings(h, w, subsampling):
     for seed, quality in ((1, 75), (2, 30), (3, 95)):

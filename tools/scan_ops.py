@@ -28,6 +28,7 @@ cases = [
     ("apply_translation (+50, -35)", lambda: ops.translate(t, 50, -35), 6),
     ("crop 3000x2000", lambda: ops.crop(t, (100, 50, 3100, 2050)), 6 * 3000 * 2000 / (H * W)),
     ("box_blur r=2", lambda: ops.box_blur(t, 2.0), 6), ("gaussian_blur_pil r=2 (defocus)", lambda: ops.gaussian_blur_pil(t, 2.0), 6),
+    ("gaussian_blur_pil r=6 (defocus severity 3)", lambda: ops.gaussian_blur_pil(t, 6.0), 6), ("gaussian_blur_pil r=10 (severity 5)", lambda: ops.gaussian_blur_pil(t, 10.0), 6),
     ("filter3x3 smooth", lambda: ops.filter3x3(t, [1, 1, 1, 1, 5, 1, 1, 1, 1], 13.0), 6),
     ("enhance_sharpness 1.5", lambda: ops.enhance_sharpness(t, 1.5), 6), ("enhance_color 1.5", lambda: ops.enhance_color(t, 1.5), 6),
     ("enhance_contrast 1.5", lambda: ops.enhance_contrast(t, 1.5), 6),
