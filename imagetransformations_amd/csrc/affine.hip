@@ -1333,11 +1333,17 @@ static int launch_bilinear_tall(const View& s, const View& d, const AffineParams
             (int64_t)s.h * s.rs < ((int64_t)1 << 32) && (int64_t)ntxq * ntyq < ((int64_t)1 << 27)) {
             AffineParams Pq = Pin;
             Pq.strip_w = 0;
-            dim3 grid((unsigned)(ntxq * ntyq), (unsigned)((d.n + afpb - 1) / afpb));
-            if (ntxq >= 16 && !knob_set(K_AFFINE_NO_STRIPS)) { Pq.strip_w = (ntxq + 7) / 8; grid.x = (unsigned)(8 * Pq.strip_w * ntyq); }
+            // 24 frames per workgroup: the tile set-up (~1500 instructions) is amortised further than at 16, the launch still
+            // has > 20 000 workgroups to drain evenly (sweep 8 ... 128 on 128 4K / 512 1080p / 32 4K frames:
+            // profiles/r03_experiments/affine_fpb_sweep.txt; 24 is the fastest or within 0.5 % everywhere)
+            const int fpbq = knob_int(K_AFFINE_FPB, 24);
+            dim3 grid((unsigned)(ntxq * ntyq), (unsigned)((d.n + fpbq - 1) / fpbq));
+            // vertical strips of tile columns per XCD from 8 columns on: vertically adjacent tiles (whose boxes overlap 2x in y)
+            // then sit a few workgroups apart on ONE L2 — at 1080p (15 columns) row-major ranges fetched every source byte twice
+            if (ntxq >= 8 && !knob_set(K_AFFINE_NO_STRIPS)) { Pq.strip_w = (ntxq + 7) / 8; grid.x = (unsigned)(8 * Pq.strip_w * ntyq); }
             const size_t lds = (size_t)4 * ((size_t)bhq * WQ_PITCH * 4 + 2 * ((size_t)bhq * nchq * 16 + 64)) + 2 * 16 * 384;
-            if (pr) hipLaunchKernelGGL((affine_bilinear_wq_kernel<true>), grid, dim3(256), lds, st, s, d, Pq, ntxq, ntyq, fpb, nchq, bhq, knob_int(K_AFFINE_MF_DBG, 0));
-            else hipLaunchKernelGGL((affine_bilinear_wq_kernel<false>), grid, dim3(256), lds, st, s, d, Pq, ntxq, ntyq, fpb, nchq, bhq, knob_int(K_AFFINE_MF_DBG, 0));
+            if (pr) hipLaunchKernelGGL((affine_bilinear_wq_kernel<true>), grid, dim3(256), lds, st, s, d, Pq, ntxq, ntyq, fpbq, nchq, bhq, knob_int(K_AFFINE_MF_DBG, 0));
+            else hipLaunchKernelGGL((affine_bilinear_wq_kernel<false>), grid, dim3(256), lds, st, s, d, Pq, ntxq, ntyq, fpbq, nchq, bhq, knob_int(K_AFFINE_MF_DBG, 0));
             return launch_status();
         }
     }
