@@ -1474,6 +1474,38 @@ int run_affine(const imgxf_view* src, const imgxf_view* dst, const double* m, in
             dim3 grid((unsigned)(ntx * nty), (unsigned)d.n);
             P.ntx_magic = (u32)((((uint64_t)1 << 32) + ntx - 1) / ntx);   // ntx, nty <= 1024: exact; 0 when ntx == 1
             const bool no_dma = knob_set(K_AFFINE_NO_DMA);
+            // round 3: 128 x 16 tiles walked over the frames, wave-private boxes, whole-line stores (affine_wq.inc) for 16-byte
+            // aligned images whose 32 x 16 block's box is at most 64 NQ_KW chunks
+            {
+                const int bwq = (int)ceil((fabs((double)P.fx[0]) * 31 + fabs((double)P.fx[1]) * 15) / 65536.0) + 3;
+                const int bhq = (int)ceil((fabs((double)P.fx[3]) * 31 + fabs((double)P.fx[4]) * 15) / 65536.0) + 3;
+                const int nchq = (bwq * 3 + 15 + 15) / 16;
+                const int kwq = (bhq * nchq + 63) / 64;
+                const int ntxq = (d.w + 127) / 128, ntyq = (d.h + 15) / 16;
+                const bool aligned = ((((uintptr_t)s.p) | (uintptr_t)s.rs | (uintptr_t)s.fs | ((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs) & 15) == 0 &&
+                                     (d.w * 3) % 16 == 0 && (s.w * 3) % 16 == 0 && s.w * 3 >= 16 &&
+                                     (int64_t)s.h * s.rs < ((int64_t)1 << 32);
+                if (aligned && !no_dma && !knob_set(K_AFFINE_NO_WQ) && kwq <= NQ_KW && (int64_t)ntxq * ntyq < ((int64_t)1 << 27)) {
+                    AffineParams Pq = P;
+                    Pq.strip_w = 0;
+                    unsigned gx = (unsigned)(ntxq * ntyq);
+                    // measured on 128 4K frames at 22.5 degrees (profiles/r03_experiments/ab_nearest_wq.txt): one frame per workgroup
+                    // (one box, one slot: 6 workgroups per CU) 1.43 ms, with XCD strips 1.49, 2 / 3 / 24 frames per workgroup
+                    // 1.77 / 1.63 / 1.71, affine_nearest_dma_kernel 1.52
+                    const int fpbq = max(1, min(knob_int(K_AFFINE_FPB, 1), d.n));
+                    const dim3 grid(gx, (unsigned)((d.n + fpbq - 1) / fpbq));
+                    const size_t nbufq = fpbq > 1 ? 2 : 1;
+                    const size_t lds = nbufq * ((size_t)4 * ((size_t)bhq * nchq * 16 + 16) + 16 * 384);
+#define IMGXF_NQ_LAUNCH(KWV) hipLaunchKernelGGL((affine_nearest_wq_kernel<KWV>), grid, dim3(256), lds, st, s, d, Pq, ntxq, ntyq, fpbq, nchq, bhq)
+                    switch (kwq) {
+                        case 1: IMGXF_NQ_LAUNCH(1); break; case 2: IMGXF_NQ_LAUNCH(2); break; case 3: IMGXF_NQ_LAUNCH(3); break;
+                        case 4: IMGXF_NQ_LAUNCH(4); break; case 5: IMGXF_NQ_LAUNCH(5); break; case 6: IMGXF_NQ_LAUNCH(6); break;
+                        case 7: IMGXF_NQ_LAUNCH(7); break; default: IMGXF_NQ_LAUNCH(8); break;
+                    }
+#undef IMGXF_NQ_LAUNCH
+                    return launch_status();
+                }
+            }
             if (bw <= 49 && bh <= 52 && !no_dma && src->w * 3 >= 16 && (src->w * 3) % 16 == 0 &&
                 ((((uintptr_t)src->data) | (uintptr_t)src->row_stride | (uintptr_t)src->frame_stride) & 15) == 0) {
                 // 32x64 tiles when their source box fits 13 chunks x 80 rows, else 32x32

@@ -100,3 +100,24 @@ def test_batched_bilinear_4k_pair(device):
     got = host(ops.affine(dev(a, device), m, (3840, 2160), ops.BILINEAR, (0, 0, 0), precise=True))
     for i in range(2):
         assert np.array_equal(got[i], O.affine_bilinear(a[i], (3840, 2160), m, fill=(0, 0, 0)))
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 96, 160), (5, 270, 480), (3, 333, 496), (2, 64, 1024)])
+def test_batched_nearest_whole_line_kernel_bit_exact(device, monkeypatch, n, h, w):
+    """apply_rotation's NEAREST rotation (/root/reference/transformation.py:198-201) through affine_nearest_wq_kernel
+    (128 x 16 tiles, wave-private boxes, whole-line stores; 16-byte aligned rows): every frame equals the oracle, for one
+    frame per workgroup (default) and for frame loops with the double-buffered boxes and the counted wait."""
+    from imagetransformations_amd import ops
+    a = np.stack([synth(760 + i, h, w) for i in range(n)])
+    t = dev(a, device)
+    for angle in (22.5, -7.0, 45.0, 90.0, 135.0, 181.0, 0.0):
+        want = np.stack([O.apply_rotation(a[i], -angle) for i in range(n)])         # = Image.rotate(angle)
+        for fpb in (None, "2", "3", "24"):
+            if fpb: monkeypatch.setenv("IMGXF_AFFINE_FPB", fpb)
+            assert np.array_equal(host(ops.rotate(t, angle)), want), (angle, fpb)
+            if fpb: monkeypatch.delenv("IMGXF_AFFINE_FPB")
+    # a non-black fill and every other frame of a larger batch
+    m = O.rotate_plan(w, h, 30.0)[1]
+    got = host(ops.affine(t[::2], m, (w, h), ops.NEAREST, (9, 8, 7)))
+    for i in range(got.shape[0]):
+        assert np.array_equal(got[i], O.affine_nearest(a[2 * i], (w, h), m, fill=(9, 8, 7)))
