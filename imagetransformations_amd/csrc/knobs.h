@@ -8,7 +8,7 @@
     X(AFFINE_NO_TALL) X(AFFINE_PK3) X(AFFINE_TILE) X(AFFINE_MF_DBG) X(AFFINE_MF_NARROW) X(AFFINE_NO_WQ) X(AFFINE_MF_WIDE) X(BOX_BYTES) X(CONV2D_NO_SEPARABLE) \
     X(FILTER3X3_BYTES) X(FX_MFMA_MIN_R) X(LANCZOS_NO_LDS) X(LANCZOS_NO_V4) X(LANCZOS_SLOW)           \
     X(MARCH4_NO_PX) X(MARCH_GROUP) X(MARCH_NO_MIXED) X(MARCH_RPW) X(MARCH_SPB) X(MARCH_TAIL)         \
-    X(MARCH_U2) X(MARCH_ORDER) X(MFMA2_BPC) X(MFMA_MIN_R) X(MFMA_NO_HREG) X(MFMA_SHAPE) X(MFMA_V1)   \
+    X(MARCH_U2) X(MARCH_ORDER) X(MFMA2_BPC) X(MFMA_MIN_R) X(MFMA_NO_HREG) X(MFMA_SHAPE) X(MFMA_V1) X(MFMA_V3)   \
     X(NO_MARCH) X(RESAMPLE_MFMA_OC) X(RESAMPLE_MFMA_WAVES) X(RESAMPLE_NO_MFMA) X(NOISE_RNG)           \
     X(NO_FAST_LEFTOVERS)
 
