@@ -1714,8 +1714,12 @@ __global__ __launch_bounds__(256) void scale_nearest_rgb4_kernel(View s, View d,
             const int x = (int)(4 * g) + k;
             int xi = xtab[x];
             xi = xi < 0 ? 0 : (xi >= s.w ? s.w - 1 : xi);
-            const u8* q = srow + xi * 3;
-            const u32 v = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16);
+            // one unaligned dword per pixel instead of three byte loads (the L1 address path bounds this gather); the
+            // last pixel of a row takes the dword ending at its last byte, so nothing past the row is read (w >= 2: host)
+            const bool last = xi == s.w - 1;
+            u32 raw;
+            __builtin_memcpy(&raw, srow + xi * 3 - (last ? 1 : 0), 4);
+            const u32 v = last ? raw >> 8 : raw & 0xffffffu;
             px[k] = (yi >= 0 && x >= xmin && x < xmax) ? v : fillw;
         }
         u32x3_a4 o;
@@ -1771,7 +1775,7 @@ IMGXF_API int imgxf_affine_scale_nearest_u8(const imgxf_view* src, const imgxf_v
     int64_t total = (int64_t)d.n * d.h * d.w;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    if (d.c == 3 && (d.w & 3) == 0 && d.n <= 65535 && (int64_t)d.h * (d.w >> 2) < 0x7fffffff &&
+    if (d.c == 3 && (d.w & 3) == 0 && src->w >= 2 && d.n <= 65535 && (int64_t)d.h * (d.w >> 2) < 0x7fffffff &&
         ((((uintptr_t)d.p) | (uintptr_t)d.rs | (uintptr_t)d.fs) & 3) == 0) {
         int64_t b4 = ((int64_t)d.h * (d.w >> 2) + 255) / 256;
         if (b4 > 4096) b4 = 4096;

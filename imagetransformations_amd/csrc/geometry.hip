@@ -150,6 +150,10 @@ __global__ __launch_bounds__(256) void rot90_tile_kernel(View s, View d, int tur
     }
 }
 
+// (Round 3 tried 128 x 16 DESTINATION tiles for packed RGB — whole-line dword-triple stores, one unaligned dword per source
+// pixel, the 128-row x 16-pixel source tile parked transposed in LDS: 0.586 ms per 16 4K frames against 0.375 ms for the
+// 32 x 32 tiles above.  A wave-level load then touches 64 source rows, and unaligned dwords cost the L1 address path as
+// much as the three byte loads they replace; profiles/r03_experiments/leftovers_round3.txt.)
 // Image.transpose(FLIP_LEFT_RIGHT / FLIP_TOP_BOTTOM): dst(y,x) = src(y, w-1-x) or src(h-1-y, x)
 __global__ __launch_bounds__(256) void flip_kernel(View s, View d, int mode) {
     const int64_t total = (int64_t)d.n * d.h * d.w;

@@ -47,3 +47,35 @@ def test_channel_permutations_every_order(device, hw, monkeypatch):
     big = dev(np.stack([synth(440 + i, 64, 96) for i in range(4)]), device)     # a strided view: every other frame, a row window
     view = big[::2, 8:40]
     assert np.array_equal(host(ops.permute_channels(view, (2, 1, 0))), host(view)[..., ::-1])
+
+
+@pytest.mark.parametrize("hw", [(16, 128), (128, 16), (37, 61), (270, 480), (2, 2), (131, 257), (5, 300)])
+def test_quarter_turns_batches_and_views_equal_numpy(device, hw):
+    """Image.transpose(ROTATE_90 / ROTATE_270) (the fast paths of Image.rotate, apply_rotation's right angles,
+    /root/reference/transformation.py:198-201): batches, partial tiles on every side, strided views; equal to np.rot90."""
+    from imagetransformations_amd import ops
+    h, w = hw
+    a = np.stack([synth(460 + i, h, w) for i in range(3)])
+    t = dev(a, device)
+    for k in (1, 3):
+        assert np.array_equal(host(ops.rot90(t, k)), np.rot90(a, k, axes=(1, 2))), k
+    if h >= 8 and w >= 12:
+        view = t[::2, 2:h - 1, 3:w - 2]                                         # rows at odd byte offsets, frame stride of two frames
+        for k in (1, 3):
+            assert np.array_equal(host(ops.rot90(view, k)), np.rot90(host(view), k, axes=(1, 2))), ("view", k)
+
+
+@pytest.mark.parametrize("hw", [(48, 64), (37, 60), (270, 480)])
+def test_nearest_zoom_dword_gather_equals_pillow(device, hw):
+    """NEAREST pure scale / translate (ImagingScaleAffine; camera-distance style zooms): the packed-RGB kernel reads one
+    unaligned dword per source pixel, the row's last pixel included."""
+    from imagetransformations_amd import ops
+    h, w = hw
+    a = np.stack([synth(480 + i, h, w) for i in range(2)])
+    t = dev(a, device)
+    for m in [(1 / 1.2, 0, w * 0.1 / 1.2, 0, 1 / 1.2, h * 0.1 / 1.2), (0.5, 0, 0, 0, 0.5, 0), (1.0, 0, 0.25, 0, 1.0, 0.75),
+              (1.7, 0, -3.2, 0, 0.6, 2.0), (1.0, 0, w - 1.5, 0, 1.0, 0)]:
+        got = host(ops.affine(t, m, (w, h), ops.NEAREST, (5, 6, 7)))
+        for i in range(2):
+            want = np.asarray(Image.fromarray(a[i]).transform((w, h), Image.AFFINE, m, fillcolor=(5, 6, 7)))
+            assert np.array_equal(got[i], want), (m, i)
