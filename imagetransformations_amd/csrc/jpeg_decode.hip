@@ -15,12 +15,11 @@
 //   jpeg_color_kernel   jdsample.c fullsize / h2v1_fancy / h2v2_fancy upsampling (edge replication as jdmainct.c does)
 //                       + jdcolor.c ycc_rgb_convert in its 16-bit fixed point, or gray -> RGB; 4 pixels per thread.
 #include "imgxf_common.h"
+#include <string.h>
 
 namespace imgxf {
 
-__constant__ u8 kDecZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,
-                                  7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
-                                  39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+__constant__ u8 kDecNatToZig[64] = {0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};      // natural position -> zigzag index
 typedef uint32_t u32_una __attribute__((aligned(1)));
 
 struct BitReader {
@@ -47,8 +46,12 @@ struct BitReader {
     __device__ __forceinline__ void skip(int n) { acc <<= n; nb -= n; }
 };
 
-// one Huffman symbol: 8-bit lookahead in LDS, then the canonical walk of jdhuff.c (jpeg_huff_decode) in global memory
-__device__ __forceinline__ int huff_symbol(BitReader& br, const uint16_t* look, const imgxf_jpeg_dec_lut* lut, bool& bad) {
+// the part of a table the canonical walk needs (codes longer than 8 bits), kept in LDS: in global memory every step of
+// the walk was two dependent memory round trips on the one busy lane
+struct HuffWalk { int32_t maxcode[18]; int32_t valoff[17]; uint8_t huffval[256]; };
+
+// one Huffman symbol: 8-bit lookahead, then the canonical walk of jdhuff.c (jpeg_huff_decode), both in LDS
+__device__ __forceinline__ int huff_symbol(BitReader& br, const uint16_t* look, const HuffWalk* lut, bool& bad) {
     const u32 e = look[br.peek(8)];
     if (e) { br.skip((int)(e >> 8)); return (int)(e & 0xffu); }
     for (int l = 9; l <= 16; ++l) {
@@ -65,15 +68,26 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const u8* __restrict__ sc
                                                        const imgxf_jpeg_dec_lut* __restrict__ luts, int16_t* __restrict__ coefs,
                                                        int32_t* __restrict__ status) {
     __shared__ uint16_t look[6][256];
-    __shared__ u8 zz[64];                          // the zigzag map and the image descriptor live in LDS: a __constant__ /
-    __shared__ imgxf_jpeg_dec_image im_s;          // global read per coefficient is a memory round trip on the one busy lane
-    zz[threadIdx.x] = kDecZigzag[threadIdx.x];
+    __shared__ HuffWalk walk[6];
+    // The image descriptor lives in LDS: a __constant__ / global read per coefficient is a memory round trip on the one busy
+    // lane.  Coefficients are stored in ZIGZAG order (the order of the stream): mapping k to its natural position here was a
+    // second LDS round trip per symbol on that lane's serial path; jpeg_idct_kernel, which has a thread per coefficient
+    // column, undoes the order when it reads.
+    __shared__ imgxf_jpeg_dec_image im_s;
     for (int i = threadIdx.x; i < (int)(sizeof(imgxf_jpeg_dec_image) / 4); i += 64) ((u32*)&im_s)[i] = ((const u32*)(images + blockIdx.x))[i];
     __syncthreads();
     const imgxf_jpeg_dec_image& im = im_s;
     for (int i = threadIdx.x; i < 6 * 256; i += 64) {
         const int slot = i >> 8, c = slot >> 1;
         if (c < im.ncomp) look[slot][i & 255] = luts[(slot & 1) ? im.comp[c].ac_tab : im.comp[c].dc_tab].look[i & 255];
+    }
+    for (int i = threadIdx.x; i < 6 * 256; i += 64) {
+        const int slot = i >> 8, c = slot >> 1, j = i & 255;
+        if (c >= im.ncomp) continue;
+        const imgxf_jpeg_dec_lut& L = luts[(slot & 1) ? im.comp[c].ac_tab : im.comp[c].dc_tab];
+        walk[slot].huffval[j] = L.huffval[j];
+        if (j < 18) walk[slot].maxcode[j] = L.maxcode[j];
+        if (j < 17) walk[slot].valoff[j] = L.valoff[j];
     }
     __syncthreads();
     const int total = im.mcux * im.mcuy;
@@ -87,8 +101,8 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const u8* __restrict__ sc
         for (int m = m0; m < m1; ++m) {
             for (int c = 0; c < im.ncomp; ++c) {
                 const imgxf_jpeg_dec_comp& cp = im.comp[c];
-                const imgxf_jpeg_dec_lut* ldc = luts + cp.dc_tab;
-                const imgxf_jpeg_dec_lut* lac = luts + cp.ac_tab;
+                const HuffWalk* ldc = &walk[2 * c];
+                const HuffWalk* lac = &walk[2 * c + 1];
                 for (int by = 0; by < cp.v; ++by)
                     for (int bx = 0; bx < cp.h; ++bx) {
                         int16_t* blk = coefs + cp.coef_off + ((int64_t)(my * cp.v + by) * cp.blocks_x + (mx * cp.h + bx)) * 64;
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const u8* __restrict__ sc
                             k += r;
                             int v = (int)br.peek(sz2); br.skip(sz2);
                             if (v < (1 << (sz2 - 1))) v -= (1 << sz2) - 1;
-                            blk[zz[k & 63]] = (int16_t)v;           // (k & 63: a corrupt run cannot leave the block)
+                            blk[k & 63] = (int16_t)v;               // zigzag position (k & 63: a corrupt run cannot leave the block)
                             ++k;
                         }
                         if (br.pos > br.len + 16) bad = true;               // ran past the data: stop believing it
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restric
         const uint16_t* q = quants + cp.quant * 64;
         int x[8], o[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = (int)blk[r * 8 + t] * (int)q[r * 8 + t];
+        for (int r = 0; r < 8; ++r) x[r] = (int)blk[kDecNatToZig[r * 8 + t]] * (int)q[r * 8 + t];      // coefficients arrive in zigzag order
         idct8(x, o, 13 - 2);
 #pragma unroll
         for (int r = 0; r < 8; ++r) ws[lb][r][t] = o[r];
@@ -288,6 +302,57 @@ static int dec_check_host(const imgxf_jpeg_dec_image* host, int n, int64_t* max_
 } // namespace imgxf
 
 using namespace imgxf;
+
+IMGXF_API int imgxf_jpeg_unstuff_host(const uint8_t* data, size_t n, size_t start, uint8_t* scan, size_t scan_cap, size_t* scan_pos,
+                                      int64_t* seg_off, int32_t* seg_len, int max_segs, int* nsegs, size_t* ecs_end) {
+    if (!data || !scan || !scan_pos || !seg_off || !seg_len || !nsegs || !ecs_end) return IMGXF_ERR_NULL;
+    if (start > n || max_segs < 1) return IMGXF_ERR_ARG;
+    size_t pos = start, out = *scan_pos;
+    int seg = 0;
+    size_t seg_begin = out;
+    bool keep = true;                                        // segments past max_segs are walked (for ecs_end) but not stored
+    auto close_segment = [&]() -> int {
+        if (!keep) return IMGXF_OK;
+        const size_t len = out - seg_begin;
+        const size_t pad = ((16 - (len & 15)) & 15) + 16;    // a refill may look a few bytes past a segment
+        if (out + pad > scan_cap || len > 0x7fffffffu) return IMGXF_ERR_WORKSPACE;
+        memset(scan + out, 0, pad);
+        seg_off[seg] = (int64_t)seg_begin;
+        seg_len[seg] = (int32_t)len;
+        out += pad;
+        ++seg;
+        seg_begin = out;
+        if (seg >= max_segs) keep = false;
+        return IMGXF_OK;
+    };
+    for (;;) {
+        const uint8_t* ff = pos < n ? (const uint8_t*)memchr(data + pos, 0xFF, n - pos) : nullptr;
+        const size_t upto = ff ? (size_t)(ff - data) : n;    // plain bytes [pos, upto)
+        const bool lone = ff && upto + 1 >= n;               // a 0xFF as the very last byte belongs to the scan
+        const size_t take = upto - pos + (lone ? 1 : 0);
+        if (keep && take) {
+            if (out + take > scan_cap) return IMGXF_ERR_WORKSPACE;
+            memcpy(scan + out, data + pos, take);
+            out += take;
+        }
+        if (!ff || lone) { pos = n; break; }
+        const uint8_t nxt = data[upto + 1];
+        if (nxt == 0x00) {                                   // stuffed zero: keep the FF
+            if (keep) { if (out + 1 > scan_cap) return IMGXF_ERR_WORKSPACE; scan[out++] = 0xFF; }
+            pos = upto + 2;
+        } else if (nxt >= 0xD0 && nxt <= 0xD7) {             // RSTn: next segment
+            const int rc = close_segment();
+            if (rc != IMGXF_OK) return rc;
+            pos = upto + 2;
+        } else { pos = upto; break; }                        // any other marker ends the scan
+    }
+    const int rc = close_segment();
+    if (rc != IMGXF_OK) return rc;
+    *scan_pos = out;
+    *nsegs = seg;
+    *ecs_end = pos;
+    return IMGXF_OK;
+}
 
 IMGXF_API int imgxf_jpeg_decode_huffman(const uint8_t* scan, const int64_t* seg_off, const int32_t* seg_len,
                                         const imgxf_jpeg_dec_image* images, int n, const imgxf_jpeg_dec_lut* luts,

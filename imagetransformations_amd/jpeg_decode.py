@@ -10,6 +10,7 @@ in this module (io_pipeline decides what to do with such a file)."""
 from __future__ import annotations
 
 import ctypes as C
+import re
 from typing import List, Sequence
 
 import numpy as np
@@ -46,8 +47,9 @@ class DecLut(C.Structure):
     _fields_ = [("look", C.c_uint16 * 256), ("maxcode", C.c_int32 * 18), ("valoff", C.c_int32 * 17), ("huffval", C.c_uint8 * 256)]
 
 
-def parse(data: bytes) -> dict:
-    """Marker segments up to the scan (jdmarker.c): frame, tables, restart interval, the entropy-coded byte range."""
+def parse(data: bytes, find_end: bool = True) -> dict:
+    """Marker segments up to the scan (jdmarker.c): frame, tables, restart interval, the entropy-coded byte range
+    (`find_end=False`: ecs = (start, None); the batched reader gets the end from imgxf_jpeg_unstuff_host's walk)."""
     if len(data) < 4 or data[0] != 0xFF or data[1] != 0xD8:
         raise UnsupportedJpeg("not a JPEG (no SOI)")
     pos, qt, huff, frame, dri = 2, {}, {}, None, 0
@@ -107,17 +109,10 @@ def parse(data: bytes) -> dict:
             if [s[0] for s in scan] != list(range(ns)):
                 raise UnsupportedJpeg("scan components out of frame order")
             start = pos + 2 + seglen
-            end = start
-            while True:
-                end = data.find(b"\xff", end)
-                if end < 0 or end + 1 >= n:
-                    end = n
-                    break
-                nxt = data[end + 1]
-                if nxt == 0x00 or 0xD0 <= nxt <= 0xD7:
-                    end += 2
-                    continue
-                break
+            end = None
+            if find_end:
+                m = _ECS_END.search(data, start)            # (a lone 0xFF as the file's last byte belongs to the scan)
+                end = m.start() if m else n
             return dict(width=w, height=h, comps=comps, qt=qt, huff=huff, scan=scan, dri=dri, ecs=(start, end))
         pos += 2 + seglen
 
@@ -157,30 +152,17 @@ def derive_lut(bits: Sequence[int], vals: bytes) -> DecLut:
     return lut
 
 
+_RST = re.compile(rb"\xff[\xd0-\xd7]")
+_ECS_END = re.compile(rb"\xff[^\x00\xd0-\xd7]")           # the first marker that is neither a stuffed zero nor RSTn ends the scan
+
+
 def _segments(raw: bytes):
-    """The entropy-coded bytes of a scan -> restart segments with the byte stuffing removed."""
+    """The entropy-coded bytes of a scan -> restart segments with the byte stuffing removed (FF 00 -> FF; FF D0..D7
+    separate segments).  `raw` is parse()'s `ecs` range: it holds no other marker.  bytes.replace / re.split run at C
+    speed; a byte-by-byte Python walk over every 0xFF was most of the reader's host time."""
     if b"\xff" not in raw:
         return [raw]
-    parts, out, i = [], [], 0
-    while True:
-        j = raw.find(b"\xff", i)
-        if j < 0 or j + 1 >= len(raw):
-            parts.append(raw[i:])
-            break
-        nxt = raw[j + 1]
-        if nxt == 0x00:
-            parts.append(raw[i:j + 1])                      # keep the 0xFF, drop the stuffed zero
-            i = j + 2
-        elif 0xD0 <= nxt <= 0xD7:
-            parts.append(raw[i:j])
-            out.append(b"".join(parts))
-            parts = []
-            i = j + 2
-        else:
-            parts.append(raw[i:j])
-            break
-    out.append(b"".join(parts))
-    return out
+    return [p.replace(b"\xff\x00", b"\xff") for p in _RST.split(raw)]
 
 
 LAST_PROFILE: dict = {}        # filled by decode(..., profile=True): seconds per stage of the last call (it synchronises)
@@ -198,39 +180,47 @@ def decode(files: Sequence[bytes], device=None, profile: bool = False) -> List[t
     if n == 0:
         return []
     t_start = time.perf_counter()
-    infos = [parse(bytes(f)) for f in files]
+    files = [bytes(f) for f in files]
+    infos = [parse(f, find_end=False) for f in files]
     luts: List[DecLut] = []
     lut_index: dict = {}
     quants: List[np.ndarray] = []
     images = (DecImage * n)()
-    seg_bytes: List[bytes] = []
-    seg_off: List[int] = []
-    seg_len: List[int] = []
     scan_pos = coef_pos = plane_pos = 0
     by_size: dict = {}
-    for i, (f, info) in enumerate(zip(files, infos)):
+    # geometry first: the number of restart segments of every scan bounds the segment tables and the scan buffer
+    geo = []
+    for info in infos:
         w, h, comps = info["width"], info["height"], info["comps"]
-        im = images[i]
-        nc = len(comps)
-        if nc == 1:
+        if len(comps) == 1:
             comps = [(comps[0][0], 1, 1, comps[0][3])]       # a one-component scan is never interleaved
         hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
+        if not (1 <= hmax <= 2 and 1 <= vmax <= 2):
+            raise UnsupportedJpeg(f"sampling factors {hmax}x{vmax}")
         mcux, mcuy = -(-w // (8 * hmax)), -(-h // (8 * vmax))
-        im.width, im.height, im.ncomp, im.hmax, im.vmax, im.mcux, im.mcuy = w, h, nc, hmax, vmax, mcux, mcuy
-        segs = _segments(bytes(f)[info["ecs"][0]:info["ecs"][1]])
         total = mcux * mcuy
         ri = info["dri"] if info["dri"] else total
-        if len(segs) < -(-total // ri):
-            raise F.ImgxfError(F.ERR_ARG, f"file {i}: the scan ends after {len(segs)} of {-(-total // ri)} restart segments", "jpeg_decode.decode")
-        segs = segs[: -(-total // ri)]
-        im.restart_interval, im.seg_first, im.seg_count = ri, len(seg_off), len(segs)
-        for sg in segs:
-            seg_off.append(scan_pos)
-            seg_len.append(len(sg))
-            seg_bytes.append(sg)
-            pad = (-len(sg)) % 16 + 16                       # a refill may look a few bytes past a segment
-            seg_bytes.append(b"\0" * pad)
-            scan_pos += len(sg) + pad
+        geo.append((comps, hmax, vmax, mcux, mcuy, ri, -(-total // ri)))
+    nseg_total = sum(g[6] for g in geo)
+    scan_cap = sum(len(f) - info["ecs"][0] + 32 * (g[6] + 1) for f, info, g in zip(files, infos, geo))
+    scan_host = torch.empty((scan_cap,), dtype=torch.uint8)
+    seg_off_h = torch.zeros((nseg_total,), dtype=torch.int64)
+    seg_len_h = torch.zeros((nseg_total,), dtype=torch.int32)
+    scan_ptr, off_ptr, len_ptr = scan_host.data_ptr(), seg_off_h.data_ptr(), seg_len_h.data_ptr()
+    pos_c, nsegs_c, end_c = C.c_size_t(0), C.c_int(0), C.c_size_t(0)
+    seg_done = 0
+    for i, (f, info, g) in enumerate(zip(files, infos, geo)):
+        w, h = info["width"], info["height"]
+        comps, hmax, vmax, mcux, mcuy, ri, want = g
+        im = images[i]
+        nc = len(comps)
+        im.width, im.height, im.ncomp, im.hmax, im.vmax, im.mcux, im.mcuy = w, h, nc, hmax, vmax, mcux, mcuy
+        F.call("imgxf_jpeg_unstuff_host", f, len(f), info["ecs"][0], scan_ptr, scan_cap, C.addressof(pos_c), off_ptr + 8 * seg_done,
+               len_ptr + 4 * seg_done, want, C.addressof(nsegs_c), C.addressof(end_c))
+        if nsegs_c.value < want:
+            raise F.ImgxfError(F.ERR_ARG, f"file {i}: the scan ends after {nsegs_c.value} of {want} restart segments", "jpeg_decode.decode")
+        im.restart_interval, im.seg_first, im.seg_count = ri, seg_done, want
+        seg_done += want
         for c, (cid, ch, cv, tq) in enumerate(comps):
             cp = im.comp[c]
             if not (1 <= ch <= 2 and 1 <= cv <= 2):
@@ -287,10 +277,9 @@ def decode(files: Sequence[bytes], device=None, profile: bool = False) -> List[t
             LAST_PROFILE["host parse + tables"] = t_host - t_start
         stream = torch.cuda.current_stream(device).cuda_stream
         out = torch.empty((out_pos,), dtype=torch.uint8, device=device)
-        scan_host = torch.frombuffer(bytearray(b"".join(seg_bytes)), dtype=torch.uint8)
-        scan_d = scan_host.to(device, non_blocking=False)
-        seg_off_d = torch.tensor(seg_off, dtype=torch.int64, device=device)
-        seg_len_d = torch.tensor(seg_len, dtype=torch.int32, device=device)
+        scan_d = scan_host[:max(16, pos_c.value)].to(device, non_blocking=False)
+        seg_off_d = seg_off_h.to(device)
+        seg_len_d = seg_len_h.to(device)
         images_d = torch.frombuffer(bytearray(bytes(images)), dtype=torch.uint8).to(device)
         lut_arr = (DecLut * len(luts))(*luts)
         luts_d = torch.frombuffer(bytearray(bytes(lut_arr)), dtype=torch.uint8).to(device)

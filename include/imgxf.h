@@ -373,7 +373,7 @@ typedef struct imgxf_jpeg_dec_comp {
     int32_t quant;              /* index into quants[] (64 uint16 each, natural order) */
     int32_t blocks_x, blocks_y; /* allocated blocks: mcux * h, mcuy * v */
     int32_t dw, dh;             /* downsampled_width / height: ceil(width * h / hmax), ceil(height * v / vmax) */
-    int64_t coef_off;           /* first int16 coefficient of the component in coefs[] ([blocks_y][blocks_x][64], natural order) */
+    int64_t coef_off;           /* first int16 coefficient of the component in coefs[] ([blocks_y][blocks_x][64], ZIGZAG order: the stream's) */
     int64_t plane_off;          /* first byte of the component's sample plane in planes[] (pitch = 8 * blocks_x) */
 } imgxf_jpeg_dec_comp;
 typedef struct imgxf_jpeg_dec_image {
@@ -396,6 +396,14 @@ typedef struct imgxf_jpeg_dec_lut {
 int imgxf_jpeg_decode_huffman(const uint8_t* scan, const int64_t* seg_off, const int32_t* seg_len,
                               const imgxf_jpeg_dec_image* images, int n, const imgxf_jpeg_dec_lut* luts,
                               int16_t* coefs, int32_t* status, void* stream);
+/* HOST helper of the reader (no device work): walks the entropy-coded bytes of one file's scan from data[start], removes
+ * the byte stuffing (FF 00 -> FF), splits at RSTn and stops at the first other marker (or at n; *ecs_end = that position).
+ * At most max_segs segments are kept (the scan's ceil(MCUs / restart interval); later ones are skipped).  Segment k is
+ * written to scan[] at seg_off[k] (16-byte aligned, taken from *scan_pos, which is advanced) with seg_len[k] bytes followed
+ * by 16 .. 31 zero bytes.  IMGXF_ERR_WORKSPACE if scan_cap is too small.  Replaces the per-byte Python walk of
+ * jpeg_decode._segments for the batched reader (load_data's Image.open, /root/reference/transformation.py:73-89). */
+int imgxf_jpeg_unstuff_host(const uint8_t* data, size_t n, size_t start, uint8_t* scan, size_t scan_cap, size_t* scan_pos,
+                            int64_t* seg_off, int32_t* seg_len, int max_segs, int* nsegs, size_t* ecs_end);
 /* Dequantisation + jpeg_idct_islow of every block of n images into their sample planes. */
 int imgxf_jpeg_decode_idct(const int16_t* coefs, const imgxf_jpeg_dec_image* images, const imgxf_jpeg_dec_image* images_host,
                            int n, const uint16_t* quants, uint8_t* planes, void* stream);
