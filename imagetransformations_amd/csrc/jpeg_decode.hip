@@ -35,6 +35,14 @@ struct BitReader {
     __device__ __forceinline__ void start(const u8* ptr, int n) {
         p = ptr; len = n; pos = 0; acc = 0; nb = 0; nextw = load(0);
     }
+    // start at bit `bit` of the segment (the parallel decoder's subsequences); consumed() = the bit the next symbol starts at
+    __device__ __forceinline__ void start_at(const u8* ptr, int n, u32 bit) {
+        p = ptr; len = n;
+        const int q = (int)(bit >> 5) * 4, r = (int)(bit & 31u);
+        acc = (uint64_t)load(q) << (32 + r);
+        nb = 32 - r; pos = q + 4; nextw = load(pos);
+    }
+    __device__ __forceinline__ u32 consumed() const { return (u32)pos * 8u - (u32)nb; }
     __device__ __forceinline__ void refill() {
         while (nb <= 32) {
             acc |= (uint64_t)nextw << (32 - nb);
@@ -49,6 +57,25 @@ struct BitReader {
 // the part of a table the canonical walk needs (codes longer than 8 bits), kept in LDS: in global memory every step of
 // the walk was two dependent memory round trips on the one busy lane
 struct HuffWalk { int32_t maxcode[18]; int32_t valoff[17]; uint8_t huffval[256]; };
+
+// the parallel decoder's parameters (jpeg_huff_par_kernel, further down)
+constexpr int PAR_BITS = 1024;                 // bits per subsequence
+constexpr int PAR_MIN_BYTES = 2048;            // images with shorter segments on average keep one lane per segment
+
+struct ParState { u32 p; u32 bk; };            // next symbol at bit p; bk = block-in-MCU * 64 + coefficient index (0: DC next)
+
+__device__ __forceinline__ bool huff_parallel_class(const imgxf_jpeg_dec_image& im, const int32_t* seg_len) {
+    // wave-uniform.  The image's first and last segment say how long its segments are (L bytes).  One lane per segment costs
+    // ceil(segments / 64) x L x 0.45 us (measured: 8.5 ms for a 19 KB scan); the workgroup takes its segments one after the
+    // other, ceil(L / 32 KB) chunks of 256 subsequences each, ~0.85 ms per chunk however few of its threads have work
+    // (22 ms for 26 chunks): 1900 byte-times per chunk.  A 4K file with a restart marker per MCU row (135 x 6 KB) stays
+    // with the lanes (8 ms against 80), one without markers (810 KB) goes to the workgroup (22 ms against 370).
+    const int64_t a = seg_len[im.seg_first], b = seg_len[im.seg_first + im.seg_count - 1];
+    const int64_t L = (a + b) / 2;
+    if (L < PAR_MIN_BYTES) return false;
+    const int64_t chunks = (L * 8 / PAR_BITS + 255) / 256 + 1;
+    return (int64_t)im.seg_count * chunks * 1900 < (int64_t)((im.seg_count + 63) / 64) * L;
+}
 
 // one Huffman symbol: 8-bit lookahead, then the canonical walk of jdhuff.c (jpeg_huff_decode), both in LDS
 __device__ __forceinline__ int huff_symbol(BitReader& br, const uint16_t* look, const HuffWalk* lut, bool& bad) {
@@ -66,7 +93,7 @@ __device__ __forceinline__ int huff_symbol(BitReader& br, const uint16_t* look, 
 __global__ __launch_bounds__(64) void jpeg_huff_kernel(const u8* __restrict__ scan, const int64_t* __restrict__ seg_off,
                                                        const int32_t* __restrict__ seg_len, const imgxf_jpeg_dec_image* __restrict__ images,
                                                        const imgxf_jpeg_dec_lut* __restrict__ luts, int16_t* __restrict__ coefs,
-                                                       int32_t* __restrict__ status) {
+                                                       int32_t* __restrict__ status, int serial_only) {
     __shared__ uint16_t look[6][256];
     __shared__ HuffWalk walk[6];
     // The image descriptor lives in LDS: a __constant__ / global read per coefficient is a memory round trip on the one busy
@@ -90,6 +117,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const u8* __restrict__ sc
         if (j < 17) walk[slot].valoff[j] = L.valoff[j];
     }
     __syncthreads();
+    if (!serial_only && huff_parallel_class(im, seg_len)) return;    // (uniform) jpeg_huff_par_kernel takes this image
     const int total = im.mcux * im.mcuy;
     bool bad = false;
     for (int s = threadIdx.x; s < im.seg_count; s += 64) {
@@ -134,6 +162,214 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const u8* __restrict__ sc
             }
             if (bad) break;                                                 // (every loop above is bounded; a bad stream ends early)
             if (++mx == im.mcux) { mx = 0; ++my; }
+        }
+    }
+    if (bad && status) atomicOr(status + blockIdx.x, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Entropy decoding INSIDE a segment in parallel (round 3, late): images whose restart segments are long — every file
+// without restart markers — are decoded by a whole workgroup each.  A Huffman stream synchronises itself: decoding from
+// a wrong bit with a wrong guess of the position inside the MCU falls in step with the true decoding after a few symbols
+// (Klein & Wiseman; Weissenberger & Schmidt, "Accelerating JPEG decompression on GPUs").  The segment is cut into
+// subsequences of PAR_BITS bits, one per thread, 256 at a time:
+//   round 0   every thread decodes its subsequence from its first bit, guessing "first block of an MCU, DC next"; the
+//             first thread of the chunk starts from the KNOWN state.  Each leaves its exit state (bit, block-in-MCU,
+//             coefficient index) for its right neighbour and the number of blocks it completed;
+//   rounds    a thread whose left neighbour's exit differs from the state it started from decodes again from there;
+//             until nobody changes.  The known prefix grows by at least one subsequence per round, so at most 256
+//             rounds; in practice the guess is wrong for one or two subsequences and 2 - 4 rounds suffice;
+//   output    an exclusive scan of the block counts gives every thread the number of the block it starts in; a last
+//             decoding writes the coefficients (zigzag order, the DC DIFFERENCE in [0]);
+//   DC        when the segment is done, a scan over its blocks per component turns the differences into values.
+// Every decoding loop is bounded by its subsequence; garbage decoded past the end of the data never reaches memory
+// (blocks beyond the segment's count are dropped) and invalid codes only count in the output pass.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ParTables {
+    const uint16_t (*look)[256];
+    const HuffWalk* walk;
+    const u8* comp_of_b;                        // block-in-MCU -> component
+    int bpm;
+};
+
+// MODE 0: states and block count only.  MODE 1: write coefficients; `g` = number of the block the subsequence starts in,
+// blocks >= G are dropped.
+template <int MODE>
+__device__ __forceinline__ ParState par_run(const u8* seg, int len, ParState st, u32 p_end, const ParTables& T, int& nblk,
+                                            int g, int G, int m0, const imgxf_jpeg_dec_image& im, const u8* bx_of_b, const u8* by_of_b,
+                                            int16_t* coefs, bool& bad) {
+    BitReader br;
+    br.start_at(seg, len, st.p);
+    int b = (int)(st.bk >> 6), k = (int)(st.bk & 63u);
+    nblk = 0;
+    int16_t* blk = nullptr;
+    auto locate = [&]() {                       // MODE 1: address of block g
+        if (g >= G) { blk = nullptr; return; }
+        const int m = m0 + g / T.bpm, my = m / im.mcux, mx = m - my * im.mcux;
+        const imgxf_jpeg_dec_comp& cp = im.comp[T.comp_of_b[b]];
+        blk = coefs + cp.coef_off + ((int64_t)(my * cp.v + by_of_b[b]) * cp.blocks_x + (mx * cp.h + bx_of_b[b])) * 64;
+    };
+    if (MODE == 1) locate();
+    while (br.consumed() < p_end) {
+        br.refill();
+        const int c = T.comp_of_b[b];
+        bool lbad = false;
+        if (k == 0) {
+            const int sz = huff_symbol(br, T.look[2 * c], &T.walk[2 * c], lbad) & 15;
+            int v = 0;
+            if (sz) {
+                br.refill();
+                v = (int)br.peek(sz); br.skip(sz);
+                if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
+            }
+            if (MODE == 1 && blk && v) blk[0] = (int16_t)v;          // the difference; jpeg_huff_par_kernel's DC pass integrates
+            k = 1;
+        } else {
+            const int rs = huff_symbol(br, T.look[2 * c + 1], &T.walk[2 * c + 1], lbad);
+            const int r = rs >> 4, sz = rs & 15;
+            if (sz == 0) {
+                k = (r == 15) ? k + 16 : 64;                         // ZRL / EOB
+            } else {
+                k += r;
+                int v = (int)br.peek(sz); br.skip(sz);
+                if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
+                if (MODE == 1 && blk) blk[k & 63] = (int16_t)v;
+                ++k;
+            }
+        }
+        if (MODE == 1 && lbad && g < G) bad = true;
+        if (k >= 64) {                                               // block complete
+            k = 0; ++nblk; ++g;
+            if (++b == T.bpm) b = 0;
+            if (MODE == 1) locate();
+        }
+    }
+    ParState ex; ex.p = br.consumed(); ex.bk = (u32)(b * 64 + k);
+    return ex;
+}
+
+__global__ __launch_bounds__(256) void jpeg_huff_par_kernel(const u8* __restrict__ scan, const int64_t* __restrict__ seg_off,
+                                                            const int32_t* __restrict__ seg_len, const imgxf_jpeg_dec_image* __restrict__ images,
+                                                            const imgxf_jpeg_dec_lut* __restrict__ luts, int16_t* __restrict__ coefs,
+                                                            int32_t* __restrict__ status) {
+    __shared__ uint16_t look[6][256];
+    __shared__ HuffWalk walk[6];
+    __shared__ imgxf_jpeg_dec_image im_s;
+    __shared__ u8 comp_of_b[12], bx_of_b[12], by_of_b[12];
+    __shared__ u32 cand_p[257], cand_bk[257];
+    __shared__ int cnt[256];
+    __shared__ int wsum[3][4];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (int)(sizeof(imgxf_jpeg_dec_image) / 4); i += 256) ((u32*)&im_s)[i] = ((const u32*)(images + blockIdx.x))[i];
+    __syncthreads();
+    const imgxf_jpeg_dec_image& im = im_s;
+    if (!huff_parallel_class(im, seg_len)) return;                   // (uniform) jpeg_huff_kernel takes this image
+    for (int i = tid; i < 6 * 256; i += 256) {
+        const int slot = i >> 8, c = slot >> 1, j = i & 255;
+        if (c >= im.ncomp) continue;
+        const imgxf_jpeg_dec_lut& L = luts[(slot & 1) ? im.comp[c].ac_tab : im.comp[c].dc_tab];
+        look[slot][j] = L.look[j];
+        walk[slot].huffval[j] = L.huffval[j];
+        if (j < 18) walk[slot].maxcode[j] = L.maxcode[j];
+        if (j < 17) walk[slot].valoff[j] = L.valoff[j];
+    }
+    int bpm = 0;
+    for (int c = 0; c < im.ncomp; ++c) bpm += im.comp[c].h * im.comp[c].v;
+    if (tid == 0) {
+        int b = 0;
+        for (int c = 0; c < im.ncomp; ++c)
+            for (int by = 0; by < im.comp[c].v; ++by)
+                for (int bx = 0; bx < im.comp[c].h; ++bx) { comp_of_b[b] = (u8)c; bx_of_b[b] = (u8)bx; by_of_b[b] = (u8)by; ++b; }
+    }
+    __syncthreads();
+    ParTables T; T.look = look; T.walk = walk; T.comp_of_b = comp_of_b; T.bpm = bpm;
+    const int total = im.mcux * im.mcuy;
+    bool bad = false;
+    for (int sgi = 0; sgi < im.seg_count; ++sgi) {                   // (uniform) the image's restart segments, one after the other
+        const u8* seg = scan + seg_off[im.seg_first + sgi];
+        const int len = seg_len[im.seg_first + sgi];
+        const u32 total_bits = (u32)len * 8u;
+        const int m0 = sgi * im.restart_interval, m1 = min(total, m0 + im.restart_interval);
+        const int G = (m1 - m0) * bpm;
+        const int nsub = (int)((total_bits + PAR_BITS - 1) / PAR_BITS);
+        ParState carry; carry.p = 0; carry.bk = 0;
+        int gbase = 0;
+        for (int c0 = 0; c0 < nsub; c0 += 256) {                     // (uniform) 256 subsequences at a time
+            const int i = c0 + tid;
+            const bool active = i < nsub;
+            const u32 p_end = min((u32)(i + 1) * PAR_BITS, total_bits);
+            ParState used; used.p = (u32)i * PAR_BITS; used.bk = 0;
+            if (tid == 0) used = carry;
+            ParState ex = used; int nb = 0;
+            if (active) ex = par_run<0>(seg, len, used, p_end, T, nb, 0, 0, 0, im, bx_of_b, by_of_b, coefs, bad);
+            cand_p[tid + 1] = ex.p; cand_bk[tid + 1] = ex.bk; cnt[tid] = active ? nb : 0;
+            __syncthreads();
+            for (int round = 0; round < 256; ++round) {              // (uniform) until every thread started from its left neighbour's exit
+                bool changed = false;
+                if (active && tid > 0) {
+                    ParState c; c.p = cand_p[tid]; c.bk = cand_bk[tid];
+                    if (c.p != used.p || c.bk != used.bk) {
+                        used = c;
+                        ex = par_run<0>(seg, len, used, p_end, T, nb, 0, 0, 0, im, bx_of_b, by_of_b, coefs, bad);
+                        changed = true;
+                    }
+                }
+                __syncthreads();                                     // every candidate has been read
+                if (changed) { cand_p[tid + 1] = ex.p; cand_bk[tid + 1] = ex.bk; cnt[tid] = nb; }
+                if (!__syncthreads_or(changed ? 1 : 0)) break;
+            }
+            // exclusive scan of the block counts: the block each subsequence starts in
+            int v = cnt[tid], incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if ((tid & 63) >= d) incl += o; }
+            if ((tid & 63) == 63) wsum[0][tid >> 6] = incl;
+            __syncthreads();
+            int wbase = 0;
+            for (int w = 0; w < (tid >> 6); ++w) wbase += wsum[0][w];
+            const int chunk_blocks = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+            const int gstart = gbase + wbase + incl - v;
+            if (active) { int nb2; par_run<1>(seg, len, used, p_end, T, nb2, gstart, G, m0, im, bx_of_b, by_of_b, coefs, bad); }
+            const int last = min(256, nsub - c0);
+            carry.p = cand_p[last]; carry.bk = cand_bk[last];
+            gbase += chunk_blocks;
+            __syncthreads();                                         // carry / wsum / cand are re-used by the next chunk
+        }
+        if (gbase < G) bad = true;                                   // the data ended before the segment's last block
+        // DC: differences -> values, per component, in the segment's block order (the output pass's stores are this
+        // workgroup's own: a barrier makes them visible)
+        __threadfence_block();
+        __syncthreads();
+        int pred[3] = {0, 0, 0};
+        for (int g0 = 0; g0 < G; g0 += 256) {                        // (uniform)
+            const int g = g0 + tid;
+            int16_t* blk = nullptr; int c = 0, d = 0;
+            if (g < G) {
+                const int b = g % bpm, m = m0 + g / bpm, my = m / im.mcux, mx = m - my * im.mcux;
+                c = comp_of_b[b];
+                const imgxf_jpeg_dec_comp& cp = im.comp[c];
+                blk = coefs + cp.coef_off + ((int64_t)(my * cp.v + by_of_b[b]) * cp.blocks_x + (mx * cp.h + bx_of_b[b])) * 64;
+                d = blk[0];
+            }
+            int inc[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                int x = (g < G && c == q) ? d : 0;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(x, dd, 64); if ((tid & 63) >= dd) x += o; }
+                inc[q] = x;
+                if ((tid & 63) == 63) wsum[q][tid >> 6] = x;
+            }
+            __syncthreads();
+            int mine = 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                int base = pred[q];
+                for (int w = 0; w < (tid >> 6); ++w) base += wsum[q][w];
+                if (c == q) mine = base + inc[q];
+                pred[q] += wsum[q][0] + wsum[q][1] + wsum[q][2] + wsum[q][3];
+            }
+            if (blk && mine != d) blk[0] = (int16_t)mine;
+            __syncthreads();
         }
     }
     if (bad && status) atomicOr(status + blockIdx.x, 1);
@@ -360,7 +596,12 @@ IMGXF_API int imgxf_jpeg_decode_huffman(const uint8_t* scan, const int64_t* seg_
     if (n < 0) return IMGXF_ERR_ARG;
     if (n == 0) return IMGXF_OK;
     if (!scan || !seg_off || !seg_len || !images || !luts || !coefs) return IMGXF_ERR_NULL;
-    hipLaunchKernelGGL(jpeg_huff_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status);
+    // images with long segments (no restart markers): a workgroup per image decodes inside the segment in parallel; the others
+    // keep a lane per segment.  Both kernels look at every image and leave the other class alone.
+    const int serial_only = knob_set(K_JPEG_SERIAL_HUFFMAN) ? 1 : 0;
+    hipLaunchKernelGGL(jpeg_huff_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status, serial_only);
+    if (!serial_only)
+        hipLaunchKernelGGL(jpeg_huff_par_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status);
     return launch_status();
 }
 

@@ -10,7 +10,7 @@
     X(MARCH4_NO_PX) X(MARCH_GROUP) X(MARCH_NO_MIXED) X(MARCH_RPW) X(MARCH_SPB) X(MARCH_TAIL)         \
     X(MARCH_U2) X(MARCH_ORDER) X(MFMA2_BPC) X(MFMA_MIN_R) X(MFMA_NO_HREG) X(MFMA_SHAPE) X(MFMA_V1) X(MFMA_V3)   \
     X(NO_MARCH) X(RESAMPLE_MFMA_OC) X(RESAMPLE_MFMA_WAVES) X(RESAMPLE_NO_MFMA) X(NOISE_RNG)           \
-    X(NO_FAST_LEFTOVERS)
+    X(NO_FAST_LEFTOVERS) X(JPEG_SERIAL_HUFFMAN)
 
 namespace imgxf {
 

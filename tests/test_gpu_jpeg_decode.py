@@ -108,3 +108,34 @@ def test_decode_then_transform_stays_on_the_device(device):
         from oracle import imgxf_oracle as O
         a = pillow_rgb(f)
         assert np.array_equal(ops.rotate(t, -22.5, ops.NEAREST, (0, 0, 0)).cpu().numpy(), O.apply_rotation(a, 22.5))
+
+
+def test_parallel_and_serial_entropy_decoders_agree_with_pillow(device, monkeypatch):
+    """Long restart segments (files without restart markers are ONE segment) are decoded by a workgroup per image that
+    synchronises 256 speculative subsequences (jpeg_huff_par_kernel); short segments keep a lane each.  Both must give
+    Pillow's pixels: every sampling, grayscale, optimised tables, scans of one to several 256-subsequence chunks, restart
+    intervals that leave long segments, mixed batches — and the same answer with the parallel decoder switched off."""
+    from imagetransformations_amd import _ffi, jpeg_decode
+    files = []
+    for i, (h, w, kw) in enumerate([(375, 500, dict(subsampling=2)), (375, 500, dict(subsampling=0, quality=95)), (480, 640, dict(subsampling=1)),
+                                    (1080, 1920, dict(subsampling=2, quality=90)), (1080, 1920, dict(subsampling=2, restart_marker_rows=17)),
+                                    (333, 517, dict(optimize=True)), (768, 1024, dict(quality=30)), (64, 64, {}), (1200, 1600, dict(quality=98, subsampling=0)),
+                                    (600, 800, dict(restart_marker_blocks=700))]):
+        files.append(jpeg_bytes(photo_like(60 + i, h, w), **kw))
+    buf = io.BytesIO(); Image.fromarray(photo_like(77, 900, 1200)).convert("L").save(buf, "JPEG", quality=85); files.append(buf.getvalue())
+    want = [np.asarray(Image.open(io.BytesIO(f)).convert("RGB")) for f in files]
+    got = [t.cpu().numpy() for t in jpeg_decode.decode(files, device)]
+    for i, (g, wnt) in enumerate(zip(got, want)):
+        assert np.array_equal(g, wnt), i
+    monkeypatch.setenv("IMGXF_JPEG_SERIAL_HUFFMAN", "1")
+    got1 = [t.cpu().numpy() for t in jpeg_decode.decode(files, device)]
+    monkeypatch.delenv("IMGXF_JPEG_SERIAL_HUFFMAN")
+    for i, (g, g1) in enumerate(zip(got, got1)):
+        assert np.array_equal(g, g1), i
+    # damaged long scans are reported, not decoded into garbage silently: cut in the middle, and a corrupted stretch
+    big = files[3]
+    info = jpeg_decode.parse(big)
+    s0, s1 = info["ecs"]
+    cut = big[:s0 + (s1 - s0) // 2] + b"\xff\xd9"
+    with pytest.raises(_ffi.ImgxfError):
+        jpeg_decode.decode([files[0], cut], device)
