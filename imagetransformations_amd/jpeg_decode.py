@@ -165,6 +165,22 @@ def _segments(raw: bytes):
     return [p.replace(b"\xff\x00", b"\xff") for p in _RST.split(raw)]
 
 
+_REFUSALS = {1: "not a JPEG (no SOI)", 2: "damaged marker structure", 3: "samples are not 8 bits",
+             4: "progressive, lossless or arithmetic coding", 5: "neither 1 nor 3 components, or a non-interleaved scan",
+             6: "the scan names an unknown component or not in frame order", 7: "sampling factors outside 1..2",
+             8: "chroma sampling other than 4:4:4, 4:2:2 (h2v1) or 4:2:0", 9: "missing quantisation table", 10: "missing Huffman table"}
+
+
+def _raise_for_status(status, n: int) -> None:
+    """imgxf_jpeg_layout_host's per-file verdicts -> the exceptions of the Python statement (first refused file)."""
+    for i in range(n):
+        code = status[i]
+        if code == 11:
+            raise F.ImgxfError(F.ERR_ARG, f"file {i}: the scan ends before its last restart segment", "jpeg_decode.decode")
+        if code:
+            raise UnsupportedJpeg(f"file {i}: {_REFUSALS.get(code, code)}")
+
+
 LAST_PROFILE: dict = {}        # filled by decode(..., profile=True): seconds per stage of the last call (it synchronises)
 
 
@@ -181,76 +197,30 @@ def decode(files: Sequence[bytes], device=None, profile: bool = False) -> List[t
         return []
     t_start = time.perf_counter()
     files = [bytes(f) for f in files]
-    infos = [parse(f, find_end=False) for f in files]
-    luts: List[DecLut] = []
-    lut_index: dict = {}
-    quants: List[np.ndarray] = []
+    # host half in C (csrc/jpeg_layout.hip: the statement of parse / derive_lut / _segments above for a whole batch)
+    ptrs = (C.c_char_p * n)(*files)
+    sizes = (C.c_size_t * n)(*map(len, files))
+    status_h = (C.c_int32 * n)()
+    n_luts, n_quants, n_segs = C.c_int(0), C.c_int(0), C.c_int(0)
+    scan_bytes, coef_total, plane_total = C.c_size_t(0), C.c_int64(0), C.c_int64(0)
+    F.call("imgxf_jpeg_layout_host", ptrs, sizes, n, None, None, 0, C.addressof(n_luts), None, 0, C.addressof(n_quants), None, 0,
+           C.addressof(scan_bytes), None, None, 0, C.addressof(n_segs), None, None, status_h)
+    _raise_for_status(status_h, n)
     images = (DecImage * n)()
-    scan_pos = coef_pos = plane_pos = 0
-    by_size: dict = {}
-    # geometry first: the number of restart segments of every scan bounds the segment tables and the scan buffer
-    geo = []
-    for info in infos:
-        w, h, comps = info["width"], info["height"], info["comps"]
-        if len(comps) == 1:
-            comps = [(comps[0][0], 1, 1, comps[0][3])]       # a one-component scan is never interleaved
-        hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
-        if not (1 <= hmax <= 2 and 1 <= vmax <= 2):
-            raise UnsupportedJpeg(f"sampling factors {hmax}x{vmax}")
-        mcux, mcuy = -(-w // (8 * hmax)), -(-h // (8 * vmax))
-        total = mcux * mcuy
-        ri = info["dri"] if info["dri"] else total
-        geo.append((comps, hmax, vmax, mcux, mcuy, ri, -(-total // ri)))
-    nseg_total = sum(g[6] for g in geo)
-    scan_cap = sum(len(f) - info["ecs"][0] + 32 * (g[6] + 1) for f, info, g in zip(files, infos, geo))
+    lut_cap, quant_cap, seg_cap, scan_cap = max(1, n_luts.value), max(1, n_quants.value), max(1, n_segs.value), max(64, scan_bytes.value)
+    lut_arr = (DecLut * lut_cap)()
+    quants_h = torch.empty((quant_cap, 64), dtype=torch.int16)
     scan_host = torch.empty((scan_cap,), dtype=torch.uint8)
-    seg_off_h = torch.zeros((nseg_total,), dtype=torch.int64)
-    seg_len_h = torch.zeros((nseg_total,), dtype=torch.int32)
-    scan_ptr, off_ptr, len_ptr = scan_host.data_ptr(), seg_off_h.data_ptr(), seg_len_h.data_ptr()
-    pos_c, nsegs_c, end_c = C.c_size_t(0), C.c_int(0), C.c_size_t(0)
-    seg_done = 0
-    for i, (f, info, g) in enumerate(zip(files, infos, geo)):
-        w, h = info["width"], info["height"]
-        comps, hmax, vmax, mcux, mcuy, ri, want = g
-        im = images[i]
-        nc = len(comps)
-        im.width, im.height, im.ncomp, im.hmax, im.vmax, im.mcux, im.mcuy = w, h, nc, hmax, vmax, mcux, mcuy
-        F.call("imgxf_jpeg_unstuff_host", f, len(f), info["ecs"][0], scan_ptr, scan_cap, C.addressof(pos_c), off_ptr + 8 * seg_done,
-               len_ptr + 4 * seg_done, want, C.addressof(nsegs_c), C.addressof(end_c))
-        if nsegs_c.value < want:
-            raise F.ImgxfError(F.ERR_ARG, f"file {i}: the scan ends after {nsegs_c.value} of {want} restart segments", "jpeg_decode.decode")
-        im.restart_interval, im.seg_first, im.seg_count = ri, seg_done, want
-        seg_done += want
-        for c, (cid, ch, cv, tq) in enumerate(comps):
-            cp = im.comp[c]
-            if not (1 <= ch <= 2 and 1 <= cv <= 2):
-                raise UnsupportedJpeg(f"sampling factors {ch}x{cv}")
-            if tq not in info["qt"]:
-                raise UnsupportedJpeg("missing quantisation table")
-            _, td, ta = info["scan"][c]
-            for cls, tid in ((0, td), (1, ta)):
-                if (cls, tid) not in info["huff"]:
-                    raise UnsupportedJpeg("missing Huffman table")
-                key = (tuple(info["huff"][(cls, tid)][0]), info["huff"][(cls, tid)][1])
-                if key not in lut_index:
-                    lut_index[key] = len(luts)
-                    luts.append(derive_lut(*info["huff"][(cls, tid)]))
-            cp.h, cp.v = ch, cv
-            cp.dc_tab = lut_index[(tuple(info["huff"][(0, td)][0]), info["huff"][(0, td)][1])]
-            cp.ac_tab = lut_index[(tuple(info["huff"][(1, ta)][0]), info["huff"][(1, ta)][1])]
-            cp.quant = len(quants)
-            quants.append(info["qt"][tq])
-            cp.blocks_x, cp.blocks_y = mcux * ch, mcuy * cv
-            cp.dw, cp.dh = -(-w * ch // hmax), -(-h * cv // vmax)
-            cp.coef_off, cp.plane_off = coef_pos, plane_pos
-            coef_pos += cp.blocks_x * cp.blocks_y * 64
-            plane_pos += cp.blocks_x * cp.blocks_y * 64
-        if nc == 3:
-            a, b, c2 = im.comp[0], im.comp[1], im.comp[2]
-            if (a.h, a.v) != (hmax, vmax) or (b.h, b.v) != (c2.h, c2.v) or (b.h * 2 != hmax and b.h != hmax) or \
-                    (b.v * 2 != vmax and b.v != vmax) or (b.h == hmax and b.v != vmax):
-                raise UnsupportedJpeg("chroma sampling other than 4:4:4, 4:2:2 (h2v1) or 4:2:0")
-        by_size.setdefault((h, w), []).append(i)
+    seg_off_h = torch.zeros((seg_cap,), dtype=torch.int64)
+    seg_len_h = torch.zeros((seg_cap,), dtype=torch.int32)
+    F.call("imgxf_jpeg_layout_host", ptrs, sizes, n, images, lut_arr, lut_cap, C.addressof(n_luts), quants_h.data_ptr(), quant_cap,
+           C.addressof(n_quants), scan_host.data_ptr(), scan_cap, C.addressof(scan_bytes), seg_off_h.data_ptr(), seg_len_h.data_ptr(), seg_cap,
+           C.addressof(n_segs), C.addressof(coef_total), C.addressof(plane_total), status_h)
+    _raise_for_status(status_h, n)
+    coef_pos, plane_pos = coef_total.value, plane_total.value
+    by_size: dict = {}
+    for i in range(n):
+        by_size.setdefault((images[i].height, images[i].width), []).append(i)
 
     # one [N, H, W, 3] tensor per size; frames are handed back in file order
     results: List[torch.Tensor] = [None] * n
@@ -277,13 +247,12 @@ def decode(files: Sequence[bytes], device=None, profile: bool = False) -> List[t
             LAST_PROFILE["host parse + tables"] = t_host - t_start
         stream = torch.cuda.current_stream(device).cuda_stream
         out = torch.empty((out_pos,), dtype=torch.uint8, device=device)
-        scan_d = scan_host[:max(16, pos_c.value)].to(device, non_blocking=False)
+        scan_d = scan_host[:max(16, scan_bytes.value)].to(device, non_blocking=False)
         seg_off_d = seg_off_h.to(device)
         seg_len_d = seg_len_h.to(device)
         images_d = torch.frombuffer(bytearray(bytes(images)), dtype=torch.uint8).to(device)
-        lut_arr = (DecLut * len(luts))(*luts)
         luts_d = torch.frombuffer(bytearray(bytes(lut_arr)), dtype=torch.uint8).to(device)
-        quants_d = torch.from_numpy(np.stack(quants).astype(np.uint16).view(np.int16)).to(device)
+        quants_d = quants_h.to(device)
         coefs = torch.zeros((coef_pos,), dtype=torch.int16, device=device)
         planes = torch.empty((plane_pos,), dtype=torch.uint8, device=device)
         status = torch.zeros((n,), dtype=torch.int32, device=device)

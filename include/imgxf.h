@@ -404,6 +404,30 @@ int imgxf_jpeg_decode_huffman(const uint8_t* scan, const int64_t* seg_off, const
  * jpeg_decode._segments for the batched reader (load_data's Image.open, /root/reference/transformation.py:73-89). */
 int imgxf_jpeg_unstuff_host(const uint8_t* data, size_t n, size_t start, uint8_t* scan, size_t scan_cap, size_t* scan_pos,
                             int64_t* seg_off, int32_t* seg_len, int max_segs, int* nsegs, size_t* ecs_end);
+/* Why a file is outside the reader's class, or damaged (status[] of imgxf_jpeg_layout_host; 0 = accepted). */
+enum { IMGXF_JPEG_E_NOT_JPEG = 1,    /* no SOI */
+       IMGXF_JPEG_E_MARKERS = 2,     /* damaged marker structure (also: SOS before SOF) */
+       IMGXF_JPEG_E_PRECISION = 3,   /* samples are not 8 bits */
+       IMGXF_JPEG_E_PROCESS = 4,     /* progressive, lossless or arithmetic coding */
+       IMGXF_JPEG_E_COMPONENTS = 5,  /* neither 1 nor 3 components, or a non-interleaved scan */
+       IMGXF_JPEG_E_SCAN_ORDER = 6,  /* the scan names an unknown component or not in frame order */
+       IMGXF_JPEG_E_SAMPLING = 7,    /* sampling factors outside 1..2 */
+       IMGXF_JPEG_E_CHROMA = 8,      /* chroma sampling other than 4:4:4, 4:2:2 (h2v1), 4:2:0 */
+       IMGXF_JPEG_E_NO_QUANT = 9,    /* a component's quantisation table is missing */
+       IMGXF_JPEG_E_NO_HUFF = 10,    /* a component's Huffman table is missing */
+       IMGXF_JPEG_E_TRUNCATED = 11   /* the scan ends before its last restart segment */ };
+/* HOST half of the reader for a batch of n files (no device work; csrc/jpeg_layout.hip): marker segments up to the scan
+ * (jdmarker.c), image / component descriptors, quantisation tables in natural order, derived Huffman tables
+ * (jpeg_make_d_derived_tbl; equal tables are shared), and the entropy-coded bytes laid out by imgxf_jpeg_unstuff_host.
+ * Pass 1, scan == NULL: only the counts — *n_segs, *n_quants, *n_luts and *scan_bytes are (bounds on) what pass 2 needs.
+ * Pass 2: images[n], luts[*n_luts], quants[*n_quants][64], scan[*scan_bytes], seg_off / seg_len[*n_segs] are filled,
+ * *coef_total / *plane_total are the sizes of coefs[] (int16) and planes[] (bytes); out_off / out_pitch of the images are
+ * left to the caller.  status[i] is 0 or the IMGXF_JPEG_E_* code of file i; the call returns IMGXF_OK unless a capacity
+ * is too small (IMGXF_ERR_WORKSPACE).  Replaces Image.open's header parsing, /root/reference/transformation.py:83. */
+int imgxf_jpeg_layout_host(const uint8_t* const* files, const size_t* sizes, int n, imgxf_jpeg_dec_image* images,
+                           imgxf_jpeg_dec_lut* luts, int lut_cap, int* n_luts, uint16_t* quants, int quant_cap, int* n_quants,
+                           uint8_t* scan, size_t scan_cap, size_t* scan_bytes, int64_t* seg_off, int32_t* seg_len, int seg_cap,
+                           int* n_segs, int64_t* coef_total, int64_t* plane_total, int32_t* status);
 /* Dequantisation + jpeg_idct_islow of every block of n images into their sample planes. */
 int imgxf_jpeg_decode_idct(const int16_t* coefs, const imgxf_jpeg_dec_image* images, const imgxf_jpeg_dec_image* images_host,
                            int n, const uint16_t* quants, uint8_t* planes, void* stream);

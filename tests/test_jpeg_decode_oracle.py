@@ -135,3 +135,76 @@ def test_host_unstuffing_and_scan_end_equal_the_bytewise_walk():
                     assert off[k] % 16 == 0 and scan[off[k]:off[k] + ln[k]].tobytes() == want[k], (raw.hex(), k)
                     assert not scan[off[k] + ln[k]:off[k] + ln[k] + 16].any()
                 assert pos.value % 16 == 0 and pos.value <= cap
+
+
+def _layout(files):
+    """imgxf_jpeg_layout_host on a batch (host code of the library; no device work)."""
+    import ctypes as C
+    from imagetransformations_amd import jpeg_decode as J, _ffi as F
+    n = len(files)
+    ptrs = (C.c_char_p * n)(*files); sizes = (C.c_size_t * n)(*map(len, files)); status = (C.c_int32 * n)()
+    nl, nq, ns = C.c_int(0), C.c_int(0), C.c_int(0)
+    sb, ct, pt = C.c_size_t(0), C.c_int64(0), C.c_int64(0)
+    F.call("imgxf_jpeg_layout_host", ptrs, sizes, n, None, None, 0, C.addressof(nl), None, 0, C.addressof(nq), None, 0, C.addressof(sb),
+           None, None, 0, C.addressof(ns), None, None, status)
+    if any(status):
+        return list(status), None
+    images = (J.DecImage * n)(); luts = (J.DecLut * max(1, nl.value))()
+    quants = np.zeros((max(1, nq.value), 64), np.uint16); scan = np.zeros(max(64, sb.value), np.uint8)
+    off = np.zeros(max(1, ns.value), np.int64); ln = np.zeros(max(1, ns.value), np.int32)
+    F.call("imgxf_jpeg_layout_host", ptrs, sizes, n, images, luts, len(luts), C.addressof(nl), quants.ctypes.data, len(quants), C.addressof(nq),
+           scan.ctypes.data, len(scan), C.addressof(sb), off.ctypes.data, ln.ctypes.data, len(off), C.addressof(ns), C.addressof(ct), C.addressof(pt), status)
+    return list(status), dict(images=images, luts=luts, n_luts=nl.value, quants=quants, scan=scan, off=off, len=ln, n_segs=ns.value,
+                              coef_total=ct.value, plane_total=pt.value)
+
+
+def test_c_host_layout_equals_the_python_statement():
+    """The batch reader's host half (csrc/jpeg_layout.hip) against parse / derive_lut / _segments on the files the reference
+    wrote and on seeded files of every sampling, table kind and restart layout; refusals carry the right reason."""
+    from imagetransformations_amd import jpeg_decode as J
+    files = [open(p, "rb").read() for p in REF[:6]]
+    for i, (h, w, kw) in enumerate([(33, 47, dict(subsampling=0)), (64, 80, dict(subsampling=1, optimize=True)), (100, 75, dict(subsampling=2, quality=30)),
+                                    (120, 160, dict(restart_marker_rows=2)), (90, 90, dict(restart_marker_blocks=5, quality=95)), (8, 8, {}), (1, 1, {})]):
+        buf = io.BytesIO(); Image.fromarray(photo_like(200 + i, h, w)).save(buf, "JPEG", **kw); files.append(buf.getvalue())
+    buf = io.BytesIO(); Image.fromarray(photo_like(9, 70, 50)).convert("L").save(buf, "JPEG"); files.append(buf.getvalue())
+    status, L = _layout(files)
+    assert not any(status)
+    seg_next = coef_next = 0
+    for i, f in enumerate(files):
+        info, im = J.parse(f), L["images"][i]
+        comps = info["comps"] if len(info["comps"]) == 3 else [(info["comps"][0][0], 1, 1, info["comps"][0][3])]
+        assert (im.width, im.height, im.ncomp) == (info["width"], info["height"], len(comps))
+        hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
+        assert (im.hmax, im.vmax, im.mcux, im.mcuy) == (hmax, vmax, -(-im.width // (8 * hmax)), -(-im.height // (8 * vmax)))
+        total = im.mcux * im.mcuy
+        ri = info["dri"] or total
+        segs = J._segments(f[info["ecs"][0]:info["ecs"][1]])[: -(-total // ri)]
+        assert (im.restart_interval, im.seg_first, im.seg_count) == (ri, seg_next, len(segs))
+        for k, sg in enumerate(segs):
+            o, n_ = int(L["off"][seg_next + k]), int(L["len"][seg_next + k])
+            assert o % 16 == 0 and L["scan"][o:o + n_].tobytes() == sg
+        seg_next += len(segs)
+        for c, (cid, ch, cv, tq) in enumerate(comps):
+            cp = im.comp[c]
+            assert (cp.h, cp.v, cp.blocks_x, cp.blocks_y) == (ch, cv, im.mcux * ch, im.mcuy * cv)
+            assert (cp.dw, cp.dh) == (-(-im.width * ch // hmax), -(-im.height * cv // vmax))
+            assert cp.coef_off == coef_next and cp.plane_off == coef_next
+            coef_next += cp.blocks_x * cp.blocks_y * 64
+            assert np.array_equal(L["quants"][cp.quant], info["qt"][tq])
+            _, td, ta = info["scan"][c]
+            for idx, key in ((cp.dc_tab, (0, td)), (cp.ac_tab, (1, ta))):
+                assert 0 <= idx < L["n_luts"]
+                assert bytes(L["luts"][idx]) == bytes(J.derive_lut(*info["huff"][key]))
+    assert L["n_segs"] == seg_next and L["coef_total"] == coef_next == L["plane_total"]
+    assert L["n_luts"] <= 4 * len(files)                      # equal tables are shared (the standard tables: 4 for the whole batch)
+    # refusals
+    good = files[6]
+    prog = io.BytesIO(); Image.fromarray(photo_like(1, 64, 64)).save(prog, "JPEG", progressive=True)
+    cmyk = io.BytesIO(); Image.fromarray(photo_like(1, 64, 64)).convert("CMYK").save(cmyk, "JPEG")
+    status, _ = _layout([good, b"not a jpeg", prog.getvalue(), cmyk.getvalue(), good[:30]])
+    assert status == [0, 1, 4, 5, 2]
+    rst = files[9]                                            # restart_marker_rows=2: cut after the first segment
+    ri = J.parse(rst)
+    first_rst = rst.index(b"\xff\xd0", ri["ecs"][0])
+    status, _ = _layout([rst[:first_rst] + b"\xff\xd9"])
+    assert status == [11]                                     # the scan ends before its last restart segment
