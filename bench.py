@@ -393,7 +393,7 @@ def ops_extras(F: int, dev, sclk_kernel):
         extras["jpeg_load_375x500"] = {"files/s": round(256 / t, 1), "Mpix/s": round(256 * 375 * 500 / t / 1e6, 1), "files": 256,
                                        "ms": round(t * 1e3, 2), "file_bytes_per_px": round(sum(len(f) for f in files) / (256 * 375 * 500), 3),
                                        "stages_ms": {k: round(v * 1e3, 2) for k, v in jpeg_decode.LAST_PROFILE.items()},
-                                       "bound": "host side (Python marker parsing and descriptors); entropy decoding runs 256 self-synchronising subsequences per image"}
+                                       "bound": "latency chain host layout -> upload -> three kernels; entropy decoding runs 256 self-synchronising subsequences per image"}
         del small, frames
     except Exception as exc:                                # noqa: BLE001
         extras["jpeg_load_375x500"] = {"error": repr(exc)[:200]}
