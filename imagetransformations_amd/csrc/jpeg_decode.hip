@@ -77,6 +77,11 @@ __device__ __forceinline__ bool huff_parallel_class(const imgxf_jpeg_dec_image& 
     return (int64_t)im.seg_count * chunks * 1900 < (int64_t)((im.seg_count + 63) / 64) * L;
 }
 
+__device__ __forceinline__ bool huff_parallel_wide(const imgxf_jpeg_dec_image& im, const int32_t* seg_len) {
+    const int64_t a = seg_len[im.seg_first], b = seg_len[im.seg_first + im.seg_count - 1];
+    return (a + b) / 2 > 2 * 256 * (PAR_BITS / 8);                       // more than two chunks of 256 subsequences
+}
+
 // one Huffman symbol: 8-bit lookahead, then the canonical walk of jdhuff.c (jpeg_huff_decode), both in LDS
 __device__ __forceinline__ int huff_symbol(BitReader& br, const uint16_t* look, const HuffWalk* lut, bool& bad) {
     const u32 e = look[br.peek(8)];
@@ -248,7 +253,10 @@ __device__ __forceinline__ ParState par_run(const u8* seg, int len, ParState st,
     return ex;
 }
 
-__global__ __launch_bounds__(256) void jpeg_huff_par_kernel(const u8* __restrict__ scan, const int64_t* __restrict__ seg_off,
+// NT = 256 threads for images whose segments fit two chunks of 256 subsequences (64 KB), 1024 threads for longer ones: a chunk
+// costs the same ~0.85 ms whatever its width (it is rounds x one subsequence), so a 4K scan of 810 KB is 7 chunks instead of 26.
+template <int NT>
+__global__ __launch_bounds__(NT) void jpeg_huff_par_kernel(const u8* __restrict__ scan, const int64_t* __restrict__ seg_off,
                                                             const int32_t* __restrict__ seg_len, const imgxf_jpeg_dec_image* __restrict__ images,
                                                             const imgxf_jpeg_dec_lut* __restrict__ luts, int16_t* __restrict__ coefs,
                                                             int32_t* __restrict__ status) {
@@ -256,15 +264,16 @@ __global__ __launch_bounds__(256) void jpeg_huff_par_kernel(const u8* __restrict
     __shared__ HuffWalk walk[6];
     __shared__ imgxf_jpeg_dec_image im_s;
     __shared__ u8 comp_of_b[12], bx_of_b[12], by_of_b[12];
-    __shared__ u32 cand_p[257], cand_bk[257];
-    __shared__ int cnt[256];
-    __shared__ int wsum[3][4];
+    __shared__ u32 cand_p[NT + 1], cand_bk[NT + 1];
+    __shared__ int cnt[NT];
+    constexpr int NW = NT / 64;
+    __shared__ int wsum[3][NW];
     const int tid = threadIdx.x;
-    for (int i = tid; i < (int)(sizeof(imgxf_jpeg_dec_image) / 4); i += 256) ((u32*)&im_s)[i] = ((const u32*)(images + blockIdx.x))[i];
+    for (int i = tid; i < (int)(sizeof(imgxf_jpeg_dec_image) / 4); i += NT) ((u32*)&im_s)[i] = ((const u32*)(images + blockIdx.x))[i];
     __syncthreads();
     const imgxf_jpeg_dec_image& im = im_s;
-    if (!huff_parallel_class(im, seg_len)) return;                   // (uniform) jpeg_huff_kernel takes this image
-    for (int i = tid; i < 6 * 256; i += 256) {
+    if (!huff_parallel_class(im, seg_len) || huff_parallel_wide(im, seg_len) != (NT == 1024)) return;    // (uniform) another kernel takes this image
+    for (int i = tid; i < 6 * 256; i += NT) {
         const int slot = i >> 8, c = slot >> 1, j = i & 255;
         if (c >= im.ncomp) continue;
         const imgxf_jpeg_dec_lut& L = luts[(slot & 1) ? im.comp[c].ac_tab : im.comp[c].dc_tab];
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256) void jpeg_huff_par_kernel(const u8* __restrict
         const int nsub = (int)((total_bits + PAR_BITS - 1) / PAR_BITS);
         ParState carry; carry.p = 0; carry.bk = 0;
         int gbase = 0;
-        for (int c0 = 0; c0 < nsub; c0 += 256) {                     // (uniform) 256 subsequences at a time
+        for (int c0 = 0; c0 < nsub; c0 += NT) {                      // (uniform) NT subsequences at a time
             const int i = c0 + tid;
             const bool active = i < nsub;
             const u32 p_end = min((u32)(i + 1) * PAR_BITS, total_bits);
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(256) void jpeg_huff_par_kernel(const u8* __restrict
             if (active) ex = par_run<0>(seg, len, used, p_end, T, nb, 0, 0, 0, im, bx_of_b, by_of_b, coefs, bad);
             cand_p[tid + 1] = ex.p; cand_bk[tid + 1] = ex.bk; cnt[tid] = active ? nb : 0;
             __syncthreads();
-            for (int round = 0; round < 256; ++round) {              // (uniform) until every thread started from its left neighbour's exit
+            for (int round = 0; round < NT; ++round) {              // (uniform) until every thread started from its left neighbour's exit
                 bool changed = false;
                 if (active && tid > 0) {
                     ParState c; c.p = cand_p[tid]; c.bk = cand_bk[tid];
@@ -326,10 +335,11 @@ __global__ __launch_bounds__(256) void jpeg_huff_par_kernel(const u8* __restrict
             __syncthreads();
             int wbase = 0;
             for (int w = 0; w < (tid >> 6); ++w) wbase += wsum[0][w];
-            const int chunk_blocks = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+            int chunk_blocks = 0;
+            for (int w = 0; w < NW; ++w) chunk_blocks += wsum[0][w];
             const int gstart = gbase + wbase + incl - v;
             if (active) { int nb2; par_run<1>(seg, len, used, p_end, T, nb2, gstart, G, m0, im, bx_of_b, by_of_b, coefs, bad); }
-            const int last = min(256, nsub - c0);
+            const int last = min(NT, nsub - c0);
             carry.p = cand_p[last]; carry.bk = cand_bk[last];
             gbase += chunk_blocks;
             __syncthreads();                                         // carry / wsum / cand are re-used by the next chunk
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(256) void jpeg_huff_par_kernel(const u8* __restrict
         __threadfence_block();
         __syncthreads();
         int pred[3] = {0, 0, 0};
-        for (int g0 = 0; g0 < G; g0 += 256) {                        // (uniform)
+        for (int g0 = 0; g0 < G; g0 += NT) {                         // (uniform)
             const int g = g0 + tid;
             int16_t* blk = nullptr; int c = 0, d = 0;
             if (g < G) {
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256) void jpeg_huff_par_kernel(const u8* __restrict
                 int base = pred[q];
                 for (int w = 0; w < (tid >> 6); ++w) base += wsum[q][w];
                 if (c == q) mine = base + inc[q];
-                pred[q] += wsum[q][0] + wsum[q][1] + wsum[q][2] + wsum[q][3];
+                for (int w = 0; w < NW; ++w) pred[q] += wsum[q][w];
             }
             if (blk && mine != d) blk[0] = (int16_t)mine;
             __syncthreads();
@@ -601,7 +611,10 @@ IMGXF_API int imgxf_jpeg_decode_huffman(const uint8_t* scan, const int64_t* seg_
     const int serial_only = knob_set(K_JPEG_SERIAL_HUFFMAN) ? 1 : 0;
     hipLaunchKernelGGL(jpeg_huff_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status, serial_only);
     if (!serial_only)
-        hipLaunchKernelGGL(jpeg_huff_par_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status);
+    {
+        hipLaunchKernelGGL((jpeg_huff_par_kernel<256>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status);
+        hipLaunchKernelGGL((jpeg_huff_par_kernel<1024>), dim3((unsigned)n), dim3(1024), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status);
+    }
     return launch_status();
 }
 
