@@ -35,6 +35,7 @@ AC_VALS = (bytes.fromhex(
     "b3b4b5b6b7b8b9bac2c3c4c5c6c7c8c9cad2d3d4d5d6d7d8d9dae2e3e4e5e6e7e8e9eaf2f3f4f5f6f7f8f9fa".replace(" ", "")))
 
 
+@lru_cache(maxsize=32)
 def quant_tables(quality: int = 75):
     """jpeg_set_quality(quality, force_baseline=TRUE): two 64-entry tables, natural order."""
     q = min(max(int(quality), 1), 100)
@@ -66,6 +67,7 @@ def tables(quality: int = 75) -> F.JpegTables:
     return t
 
 
+@lru_cache(maxsize=64)
 def header(width: int, height: int, quality: int = 75) -> bytes:
     """SOI, APP0 (JFIF 1.01, no density), DQT ×2, SOF0 (Y 2×2, Cb / Cr 1×1), DHT ×4, SOS — jcmarker.c's order."""
     if not (0 < width < 65536 and 0 < height < 65536):

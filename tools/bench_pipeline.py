@@ -26,14 +26,17 @@ try:
                             ("device decode, device encode, NumPy noise", dict(decoder="device", encoder="device"), "numpy"),
                             ("device decode, device encode, device noise", dict(decoder="device", encoder="device"), "device"),
                             ("Pillow decode, Pillow encode, device noise", dict(), "device")):
+        if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+            continue
         dst = tempfile.mkdtemp(prefix="imgxf_pipe_out_")
         try:
             T.NOISE_RNG = noise
             random.seed(0); np.random.seed(0)
-            if name.startswith("Pillow decode, Pillow encode, NumPy"):       # warm-up of kernels, plans and pinned blocks
-                IO.run_directory(src, dst, chunk_images=64, workers=16, **kw)
-                shutil.rmtree(dst); os.makedirs(dst)
-                random.seed(0); np.random.seed(0)
+            # every configuration runs twice and the second run is reported: the first one pays its own warm-up (kernels and
+            # torch ops not launched before, pinned blocks of its sizes, the writer's and reader's tables)
+            IO.run_directory(src, dst, chunk_images=256, workers=16, **kw)
+            shutil.rmtree(dst); os.makedirs(dst)
+            random.seed(0); np.random.seed(0)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             files = IO.run_directory(src, dst, chunk_images=256, workers=16, **kw)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
