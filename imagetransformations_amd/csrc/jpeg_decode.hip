@@ -549,57 +549,6 @@ static int dec_check_host(const imgxf_jpeg_dec_image* host, int n, int64_t* max_
 
 using namespace imgxf;
 
-IMGXF_API int imgxf_jpeg_unstuff_host(const uint8_t* data, size_t n, size_t start, uint8_t* scan, size_t scan_cap, size_t* scan_pos,
-                                      int64_t* seg_off, int32_t* seg_len, int max_segs, int* nsegs, size_t* ecs_end) {
-    if (!data || !scan || !scan_pos || !seg_off || !seg_len || !nsegs || !ecs_end) return IMGXF_ERR_NULL;
-    if (start > n || max_segs < 1) return IMGXF_ERR_ARG;
-    size_t pos = start, out = *scan_pos;
-    int seg = 0;
-    size_t seg_begin = out;
-    bool keep = true;                                        // segments past max_segs are walked (for ecs_end) but not stored
-    auto close_segment = [&]() -> int {
-        if (!keep) return IMGXF_OK;
-        const size_t len = out - seg_begin;
-        const size_t pad = ((16 - (len & 15)) & 15) + 16;    // a refill may look a few bytes past a segment
-        if (out + pad > scan_cap || len > 0x7fffffffu) return IMGXF_ERR_WORKSPACE;
-        memset(scan + out, 0, pad);
-        seg_off[seg] = (int64_t)seg_begin;
-        seg_len[seg] = (int32_t)len;
-        out += pad;
-        ++seg;
-        seg_begin = out;
-        if (seg >= max_segs) keep = false;
-        return IMGXF_OK;
-    };
-    for (;;) {
-        const uint8_t* ff = pos < n ? (const uint8_t*)memchr(data + pos, 0xFF, n - pos) : nullptr;
-        const size_t upto = ff ? (size_t)(ff - data) : n;    // plain bytes [pos, upto)
-        const bool lone = ff && upto + 1 >= n;               // a 0xFF as the very last byte belongs to the scan
-        const size_t take = upto - pos + (lone ? 1 : 0);
-        if (keep && take) {
-            if (out + take > scan_cap) return IMGXF_ERR_WORKSPACE;
-            memcpy(scan + out, data + pos, take);
-            out += take;
-        }
-        if (!ff || lone) { pos = n; break; }
-        const uint8_t nxt = data[upto + 1];
-        if (nxt == 0x00) {                                   // stuffed zero: keep the FF
-            if (keep) { if (out + 1 > scan_cap) return IMGXF_ERR_WORKSPACE; scan[out++] = 0xFF; }
-            pos = upto + 2;
-        } else if (nxt >= 0xD0 && nxt <= 0xD7) {             // RSTn: next segment
-            const int rc = close_segment();
-            if (rc != IMGXF_OK) return rc;
-            pos = upto + 2;
-        } else { pos = upto; break; }                        // any other marker ends the scan
-    }
-    const int rc = close_segment();
-    if (rc != IMGXF_OK) return rc;
-    *scan_pos = out;
-    *nsegs = seg;
-    *ecs_end = pos;
-    return IMGXF_OK;
-}
-
 IMGXF_API int imgxf_jpeg_decode_huffman(const uint8_t* scan, const int64_t* seg_off, const int32_t* seg_len,
                                         const imgxf_jpeg_dec_image* images, int n, const imgxf_jpeg_dec_lut* luts,
                                         int16_t* coefs, int32_t* status, void* stream) {
