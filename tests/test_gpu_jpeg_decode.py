@@ -139,3 +139,33 @@ def test_parallel_and_serial_entropy_decoders_agree_with_pillow(device, monkeypa
     cut = big[:s0 + (s1 - s0) // 2] + b"\xff\xd9"
     with pytest.raises(_ffi.ImgxfError):
         jpeg_decode.decode([files[0], cut], device)
+
+
+def test_corrupted_scans_are_reported_or_decoded_never_fatal(device):
+    """Byte flips, random stretches and truncations inside the entropy-coded data, for files of both decoder classes (one long
+    segment / a restart marker per MCU row): every call returns frames or raises; afterwards good files still decode."""
+    from imagetransformations_amd import _ffi, jpeg_decode
+    rng = np.random.default_rng(3)
+    img = photo_like(90, 400, 560)
+    seeds = [jpeg_bytes(img, quality=85), jpeg_bytes(img, quality=85, restart_marker_rows=1), jpeg_bytes(img, quality=60, subsampling=0)]
+    reported = 0
+    for c in range(24):
+        batch = []
+        for f in seeds:
+            s0, s1 = jpeg_decode.parse(f)["ecs"]
+            g = bytearray(f)
+            if c % 3 == 0:
+                for _ in range(int(rng.integers(1, 30))):
+                    g[int(rng.integers(s0, s1))] = int(rng.integers(0, 256))
+            elif c % 3 == 1:
+                g = g[:int(rng.integers(s0, s1))] + b"\xff\xd9"
+            else:
+                a = int(rng.integers(s0, s1 - 64)); g[a:a + 64] = bytes(rng.integers(0, 256, 64, dtype=np.uint8))
+            batch.append(bytes(g))
+        try:
+            jpeg_decode.decode(batch, device)
+        except (_ffi.ImgxfError, jpeg_decode.UnsupportedJpeg):
+            reported += 1
+    assert reported >= 12
+    for t, f in zip(jpeg_decode.decode(seeds, device), seeds):
+        assert np.array_equal(t.cpu().numpy(), np.asarray(Image.open(io.BytesIO(f)).convert("RGB")))

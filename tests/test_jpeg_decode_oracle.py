@@ -208,3 +208,23 @@ def test_c_host_layout_equals_the_python_statement():
     first_rst = rst.index(b"\xff\xd0", ri["ecs"][0])
     status, _ = _layout([rst[:first_rst] + b"\xff\xd9"])
     assert status == [11]                                     # the scan ends before its last restart segment
+
+
+def test_c_host_layout_survives_every_truncation_and_byte_flips():
+    """The host half reads untrusted files: every prefix of small files and seeded byte flips go through both passes; a file
+    is accepted or refused with a reason, the neighbour in the batch is unaffected (tools/fuzz_jpeg_layout.py runs the same
+    under AddressSanitizer)."""
+    rng = np.random.default_rng(8)
+    base = []
+    for i, kw in enumerate([dict(), dict(subsampling=0, optimize=True), dict(restart_marker_rows=1)]):
+        buf = io.BytesIO(); Image.fromarray(photo_like(300 + i, 24, 40)).save(buf, "JPEG", **kw); base.append(buf.getvalue())
+    for f in base:
+        cases = [f[:k] for k in range(0, len(f), 2)]
+        for _ in range(150):
+            g = bytearray(f)
+            for _ in range(int(rng.integers(1, 4))):
+                g[int(rng.integers(0, len(g)))] = int(rng.integers(0, 256))
+            cases.append(bytes(g))
+        for g in cases:
+            status, _ = _layout([g, base[0]])
+            assert status[1] == 0 and 0 <= status[0] <= 11
