@@ -15,6 +15,8 @@ results are still on their way back, and synchronise once per result when it bui
 """
 from __future__ import annotations
 
+import os
+import weakref
 from typing import Sequence
 
 import numpy as np
@@ -69,3 +71,59 @@ class Download:
 
 def download(t: torch.Tensor) -> Download:
     return Download(t)
+
+
+# ---- PIL images on top of the pinned blocks (the PIL end of the batched drivers) ----------------------------------
+# Image.fromarray costs 90 us for a 375 x 500 RGB frame — a zero fill of the new image plus a per-pixel repack of packed
+# RGB into Pillow's 4-byte RGBX storage — which was 65 % of the batched driver's wall time once the noise draw had moved
+# to the device.  Pillow can instead MAP a buffer that already has its storage layout: the device expands the results to
+# RGBX (one more byte per pixel over PCIe), Image.frombuffer("RGBX", ...) wraps a frame of the pinned block without
+# copying, and ImagingCore.setmode relabels it RGB in place (the call Image.putalpha uses).  The image is flagged
+# read-only, so Pillow copies it before any in-place change; it keeps its block alive.  Pinned memory held this way is
+# bounded: beyond ZERO_COPY_BUDGET bytes of live images the drivers fall back to Image.fromarray.
+ZERO_COPY_BUDGET = int(os.environ.get("IMGXF_PIL_ZERO_COPY_BYTES", str(4 << 30)))
+_zc_live = 0
+_zc_ok = None
+
+
+def _zero_copy_probe() -> bool:
+    """Does this Pillow map RGBX buffers and relabel them RGB in place?  (Checked once, on a 2 x 3 image.)"""
+    try:
+        from PIL import Image
+        a = np.arange(24, dtype=np.uint8).reshape(2, 3, 4).copy()
+        im = Image.frombuffer("RGBX", (3, 2), a, "raw", "RGBX", 0, 1)
+        im.im.setmode("RGB")
+        im._mode = im.im.mode
+        ok = im.mode == "RGB" and np.array_equal(np.asarray(im), a[..., :3])
+        a[0, 0, 0] = 200
+        return bool(ok and np.asarray(im)[0, 0, 0] == 200 and im.readonly)
+    except Exception:
+        return False
+
+
+def zero_copy_reserve(nbytes: int) -> bool:
+    """Room for `nbytes` more of pinned memory under live PIL images?  Reserves them if so."""
+    global _zc_live, _zc_ok
+    if _zc_ok is None:
+        _zc_ok = ZERO_COPY_BUDGET > 0 and _zero_copy_probe()
+    if not _zc_ok or _zc_live + nbytes > ZERO_COPY_BUDGET:
+        return False
+    _zc_live += nbytes
+    return True
+
+
+def _zero_copy_release(nbytes: int) -> None:
+    global _zc_live
+    _zc_live -= nbytes
+
+
+def image_from_rgbx(frame: np.ndarray):
+    """[H, W, 4] uint8 RGBX view of a pinned block (bytes reserved with zero_copy_reserve) -> mode-"RGB" PIL image that
+    shares it."""
+    from PIL import Image
+    h, w = frame.shape[:2]
+    im = Image.frombuffer("RGBX", (w, h), frame, "raw", "RGBX", 0, 1)
+    im.im.setmode("RGB")
+    im._mode = im.im.mode
+    weakref.finalize(im, _zero_copy_release, frame.nbytes)
+    return im

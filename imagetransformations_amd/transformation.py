@@ -381,10 +381,10 @@ def _is_rgb(img) -> bool:
 
 def _collect(item, results) -> int:
     """Wait for one queued copy back and build its PIL images; returns the bytes it held."""
-    dl, entries = item
+    dl, entries, rgbx = item
     host = dl.numpy()
     for j, (_, i, k) in enumerate(entries):
-        results[i][k] = Image.fromarray(host[j])
+        results[i][k] = staging.image_from_rgbx(host[j]) if rgbx else Image.fromarray(host[j])
     return host.nbytes
 
 
@@ -468,7 +468,10 @@ def apply_all_transformations_batched_named(images, _sink=None):
             # queue the copy back and keep launching: the host waits per result only when it builds the images.
             # The window of copies in flight is bounded (staging.PENDING_BUDGET bytes of pinned memory): beyond
             # it the oldest results are turned into images before the next group is queued
-            pending.append((staging.download(out), entries))
+            # RGB frames go back as RGBX and become PIL images that share the pinned block (staging.image_from_rgbx)
+            rgbx = out.dim() == 4 and out.shape[-1] == 3 and out.dtype == torch.uint8 and \
+                staging.zero_copy_reserve(out.shape[0] * out.shape[1] * out.shape[2] * 4)
+            pending.append((staging.download(ops.permute_channels(out, (0, 1, 2, 2)) if rgbx else out), entries, rgbx))
             queued += out.numel()
             while queued > staging.PENDING_BUDGET and len(pending) > 1:
                 queued -= _collect(pending.pop(0), results)
