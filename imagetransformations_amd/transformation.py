@@ -52,7 +52,10 @@ def _upload(img: Image.Image) -> torch.Tensor:
 
 
 def _download(t: torch.Tensor) -> Image.Image:
-    """Image.fromarray(device tensor): asynchronous copy into pinned memory, wait for that copy only."""
+    """Image.fromarray(device tensor): asynchronous copy into pinned memory, wait for that copy only.  An RGB frame goes
+    back as RGBX and becomes a PIL image mapped onto the pinned block (staging.image_from_rgbx) while its budget lasts."""
+    if t.dim() == 3 and t.shape[-1] == 3 and t.dtype == torch.uint8 and staging.zero_copy_reserve(t.shape[0] * t.shape[1] * 4):
+        return staging.image_from_rgbx(staging.download(ops.permute_channels(t, (0, 1, 2, 2))).numpy())
     return Image.fromarray(staging.download(t).numpy())
 
 
