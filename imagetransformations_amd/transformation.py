@@ -352,7 +352,7 @@ def apply_all_transformations_batched_to_files(images, out_dir: str) -> List[str
             shape = tuple(out.shape[1:])
             slot = held.setdefault(shape, [[], [], 0])
             slot[0].append(out); slot[1].extend(names); slot[2] += out.shape[0]
-            if slot[2] >= SINK_FRAMES:
+            if slot[2] >= SINK_FRAMES or slot[2] * out[0].numel() >= SINK_BYTES:
                 flush(shape)
         else:                                             # another format: Pillow writes it
             host = staging.download(out).numpy()
@@ -370,7 +370,8 @@ def apply_all_transformations_batched_to_files(images, out_dir: str) -> List[str
     return [name for name, _ in named]
 
 
-SINK_FRAMES = 1024                                        # frames of one shape per writer call in the device-save drivers
+SINK_FRAMES = 1024                                        # frames of one shape per writer call in the device-save drivers ...
+SINK_BYTES = 2 << 30                                      # ... or this many bytes of them (4K frames: 86 per call), whichever comes first
 
 
 def _size_of(img):
@@ -384,7 +385,8 @@ def _is_rgb(img) -> bool:
 
 def _collect(item, results) -> int:
     """Wait for one queued copy back and build its PIL images; returns the bytes it held."""
-    dl, entries, rgbx = item
+    dl, entries, *flag = item                             # (download, entries[, frames are RGBX for staging.image_from_rgbx])
+    rgbx = bool(flag and flag[0])
     host = dl.numpy()
     for j, (_, i, k) in enumerate(entries):
         results[i][k] = staging.image_from_rgbx(host[j]) if rgbx else Image.fromarray(host[j])
