@@ -269,9 +269,9 @@ def decode(files: Sequence[bytes], device=None, profile: bool = False) -> List[t
     if bad:
         raise F.ImgxfError(F.ERR_ARG, f"damaged entropy-coded data in file(s) {bad}", "jpeg_decode.decode")
     for off, cnt, h, w, members in spans:
-        batch = out[off:off + cnt * h * w * 3].view(cnt, h, w, 3)
+        frames = out[off:off + cnt * h * w * 3].view(cnt, h, w, 3).unbind(0)     # (one call: indexing frame by frame costs 3 us each)
         for j, i in enumerate(members):
-            results[i] = batch[j]
+            results[i] = frames[j]
     return results
 
 
