@@ -64,22 +64,26 @@ constexpr int PAR_MIN_BYTES = 2048;            // images with shorter segments o
 
 struct ParState { u32 p; u32 bk; };            // next symbol at bit p; bk = block-in-MCU * 64 + coefficient index (0: DC next)
 
-__device__ __forceinline__ bool huff_parallel_class(const imgxf_jpeg_dec_image& im, const int32_t* seg_len) {
-    // wave-uniform.  The image's first and last segment say how long its segments are (L bytes).  One lane per segment costs
-    // ceil(segments / 64) x L x 0.45 us (measured: 8.5 ms for a 19 KB scan); the workgroup takes its segments one after the
-    // other, ceil(L / 32 KB) chunks of 256 subsequences each, ~0.85 ms per chunk however few of its threads have work
-    // (22 ms for 26 chunks): 1900 byte-times per chunk.  A 4K file with a restart marker per MCU row (135 x 6 KB) stays
-    // with the lanes (8 ms against 80), one without markers (810 KB) goes to the workgroup (22 ms against 370).
+// Which kernel decodes an image (wave-uniform; every kernel evaluates it and leaves the other classes alone).  The image's
+// first and last segment say how long its segments are (L bytes):
+//   0  a LANE per segment (jpeg_huff_kernel): short segments.  Costs ceil(segments / 64) x L x 0.45 us (measured: 8.5 ms for
+//      a 19 KB scan);
+//   1  a WAVE per segment (jpeg_huff_par_kernel<64, true>, PERSEG_SLOTS workgroups per image taking its segments in turn):
+//      several segments of 2 .. 16 KB — a 4K file with a restart marker per MCU row is 135 x 6 KB;
+//   2  a WORKGROUP of 256 per image, its segments one after the other, 256 subsequences per chunk (~0.85 ms per chunk however
+//      few of its threads have work): one or a few segments up to 64 KB — every ImageNet-size file without restart markers;
+//   3  a workgroup of 1024 per image: longer segments (a 4K scan of 810 KB is 7 chunks instead of 26).
+constexpr int PERSEG_SLOTS = 32;
+enum { HUFF_LANES = 0, HUFF_WAVE_PER_SEGMENT = 1, HUFF_WG256 = 2, HUFF_WG1024 = 3 };
+
+__device__ __forceinline__ int huff_class(const imgxf_jpeg_dec_image& im, const int32_t* seg_len) {
     const int64_t a = seg_len[im.seg_first], b = seg_len[im.seg_first + im.seg_count - 1];
     const int64_t L = (a + b) / 2;
-    if (L < PAR_MIN_BYTES) return false;
+    if (L < PAR_MIN_BYTES) return HUFF_LANES;
+    if (L > 2 * 256 * (PAR_BITS / 8)) return HUFF_WG1024;
+    if (im.seg_count >= 2 && L <= 16384) return HUFF_WAVE_PER_SEGMENT;
     const int64_t chunks = (L * 8 / PAR_BITS + 255) / 256 + 1;
-    return (int64_t)im.seg_count * chunks * 1900 < (int64_t)((im.seg_count + 63) / 64) * L;
-}
-
-__device__ __forceinline__ bool huff_parallel_wide(const imgxf_jpeg_dec_image& im, const int32_t* seg_len) {
-    const int64_t a = seg_len[im.seg_first], b = seg_len[im.seg_first + im.seg_count - 1];
-    return (a + b) / 2 > 2 * 256 * (PAR_BITS / 8);                       // more than two chunks of 256 subsequences
+    return (int64_t)im.seg_count * chunks * 1900 < (int64_t)((im.seg_count + 63) / 64) * L ? HUFF_WG256 : HUFF_LANES;
 }
 
 // one Huffman symbol: 8-bit lookahead, then the canonical walk of jdhuff.c (jpeg_huff_decode), both in LDS
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const u8* __restrict__ sc
         if (j < 17) walk[slot].valoff[j] = L.valoff[j];
     }
     __syncthreads();
-    if (!serial_only && huff_parallel_class(im, seg_len)) return;    // (uniform) jpeg_huff_par_kernel takes this image
+    if (!serial_only && huff_class(im, seg_len) != HUFF_LANES) return;   // (uniform) jpeg_huff_par_kernel takes this image
     const int total = im.mcux * im.mcuy;
     bool bad = false;
     for (int s = threadIdx.x; s < im.seg_count; s += 64) {
@@ -255,7 +259,9 @@ __device__ __forceinline__ ParState par_run(const u8* seg, int len, ParState st,
 
 // NT = 256 threads for images whose segments fit two chunks of 256 subsequences (64 KB), 1024 threads for longer ones: a chunk
 // costs the same ~0.85 ms whatever its width (it is rounds x one subsequence), so a 4K scan of 810 KB is 7 chunks instead of 26.
-template <int NT>
+// PERSEG: the workgroup (one wave, NT = 64) is slot blockIdx.y of PERSEG_SLOTS for its image and takes segments blockIdx.y,
+// blockIdx.y + PERSEG_SLOTS, ...
+template <int NT, bool PERSEG>
 __global__ __launch_bounds__(NT) void jpeg_huff_par_kernel(const u8* __restrict__ scan, const int64_t* __restrict__ seg_off,
                                                             const int32_t* __restrict__ seg_len, const imgxf_jpeg_dec_image* __restrict__ images,
                                                             const imgxf_jpeg_dec_lut* __restrict__ luts, int16_t* __restrict__ coefs,
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(NT) void jpeg_huff_par_kernel(const u8* __restrict_
     for (int i = tid; i < (int)(sizeof(imgxf_jpeg_dec_image) / 4); i += NT) ((u32*)&im_s)[i] = ((const u32*)(images + blockIdx.x))[i];
     __syncthreads();
     const imgxf_jpeg_dec_image& im = im_s;
-    if (!huff_parallel_class(im, seg_len) || huff_parallel_wide(im, seg_len) != (NT == 1024)) return;    // (uniform) another kernel takes this image
+    if (huff_class(im, seg_len) != (PERSEG ? HUFF_WAVE_PER_SEGMENT : (NT == 1024 ? HUFF_WG1024 : HUFF_WG256))) return;    // (uniform) another kernel takes this image
     for (int i = tid; i < 6 * 256; i += NT) {
         const int slot = i >> 8, c = slot >> 1, j = i & 255;
         if (c >= im.ncomp) continue;
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(NT) void jpeg_huff_par_kernel(const u8* __restrict_
     ParTables T; T.look = look; T.walk = walk; T.comp_of_b = comp_of_b; T.bpm = bpm;
     const int total = im.mcux * im.mcuy;
     bool bad = false;
-    for (int sgi = 0; sgi < im.seg_count; ++sgi) {                   // (uniform) the image's restart segments, one after the other
+    for (int sgi = PERSEG ? (int)blockIdx.y : 0; sgi < im.seg_count; sgi += PERSEG ? PERSEG_SLOTS : 1) {    // (uniform) the image's restart segments, one after the other
         const u8* seg = scan + seg_off[im.seg_first + sgi];
         const int len = seg_len[im.seg_first + sgi];
         const u32 total_bits = (u32)len * 8u;
@@ -561,8 +567,9 @@ IMGXF_API int imgxf_jpeg_decode_huffman(const uint8_t* scan, const int64_t* seg_
     hipLaunchKernelGGL(jpeg_huff_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status, serial_only);
     if (!serial_only)
     {
-        hipLaunchKernelGGL((jpeg_huff_par_kernel<256>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status);
-        hipLaunchKernelGGL((jpeg_huff_par_kernel<1024>), dim3((unsigned)n), dim3(1024), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status);
+        hipLaunchKernelGGL((jpeg_huff_par_kernel<256, false>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status);
+        hipLaunchKernelGGL((jpeg_huff_par_kernel<1024, false>), dim3((unsigned)n), dim3(1024), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status);
+        hipLaunchKernelGGL((jpeg_huff_par_kernel<64, true>), dim3((unsigned)n, PERSEG_SLOTS), dim3(64), 0, (hipStream_t)stream, scan, seg_off, seg_len, images, luts, coefs, status);
     }
     return launch_status();
 }
