@@ -112,7 +112,8 @@ def test_decode_then_transform_stays_on_the_device(device):
 
 def test_parallel_and_serial_entropy_decoders_agree_with_pillow(device, monkeypatch):
     """Long restart segments (files without restart markers are ONE segment) are decoded by a workgroup per image that
-    synchronises 256 speculative subsequences (jpeg_huff_par_kernel); short segments keep a lane each.  Both must give
+    synchronises 256 / 1024 speculative subsequences (jpeg_huff_par_kernel), several mid-size segments by a wave each; short
+    segments keep a lane each.  Both must give
     Pillow's pixels: every sampling, grayscale, optimised tables, scans of one to several 256-subsequence chunks, restart
     intervals that leave long segments, mixed batches — and the same answer with the parallel decoder switched off."""
     from imagetransformations_amd import _ffi, jpeg_decode
@@ -120,7 +121,9 @@ def test_parallel_and_serial_entropy_decoders_agree_with_pillow(device, monkeypa
     for i, (h, w, kw) in enumerate([(375, 500, dict(subsampling=2)), (375, 500, dict(subsampling=0, quality=95)), (480, 640, dict(subsampling=1)),
                                     (1080, 1920, dict(subsampling=2, quality=90)), (1080, 1920, dict(subsampling=2, restart_marker_rows=17)),
                                     (333, 517, dict(optimize=True)), (768, 1024, dict(quality=30)), (64, 64, {}), (1200, 1600, dict(quality=98, subsampling=0)),
-                                    (600, 800, dict(restart_marker_blocks=700))]):
+                                    (600, 800, dict(restart_marker_blocks=700)),
+                                    (1080, 1920, dict(restart_marker_rows=1, quality=90)),          # 68 segments of a few KB: a wave per segment
+                                    (720, 1280, dict(restart_marker_rows=2, subsampling=0)), (400, 2000, dict(restart_marker_blocks=40, quality=95))]):
         files.append(jpeg_bytes(photo_like(60 + i, h, w), **kw))
     buf = io.BytesIO(); Image.fromarray(photo_like(77, 900, 1200)).convert("L").save(buf, "JPEG", quality=85); files.append(buf.getvalue())
     want = [np.asarray(Image.open(io.BytesIO(f)).convert("RGB")) for f in files]
