@@ -1,0 +1,179 @@
+"""NumPy's legacy normal stream, generated on the device: `np.random.normal(0, s, shape)` of the global RandomState
+(`apply_gaussian_noise`, /root/reference/transformation.py:273-275; `TransformationPool.gaussian_noise`,
+pipenline/cifar_image_transformations.py:39-48) for the SAME seed gives the SAME numbers — without the host drawing
+them (10 ms per 375 x 500 image, which was most of the drivers' wall time).
+
+What NumPy does (numpy/random/src/legacy/legacy-distributions.c, mt19937.c; restated):
+  * MT19937: 624 state words; word k of the output stream is the TEMPERED word k of the state sequence; a block of 624
+    new state words is computed from the previous block (`imgxf_mt19937_blocks`, one workgroup, sequential in the block
+    index) — the raw state sequence is kept, so the generator's state at any position of the stream is simply a slice;
+  * legacy_double: a = next >> 5, b = next >> 6, (a * 2^26 + b) / 2^53;
+  * legacy_gauss (polar Box-Muller): x1 = 2 u - 1, x2 = 2 u' - 1, r2 = x1^2 + x2^2, REJECTED unless 0 < r2 < 1; else
+    f = sqrt(-2 log(r2) / r2); the call returns f x2 and keeps f x1 for the next call (has_gauss);
+  * normal = loc + scale * gauss, then the caller's .astype(float32).
+Groups of four words are independent: all of them are evaluated at once, a prefix sum of the acceptance flags says
+which ones the sequential loop would have used, and the position of the last one used is where the stream — and with it
+the generator state handed back to NumPy — continues.
+
+Exactness: every step is integer arithmetic or a correctly rounded IEEE operation except `log`, where the device's and
+glibc's may differ in the last bit.  The float32 result can only differ if the double lies within 2^-46 (relative) of a
+float32 rounding boundary — one sample in two million; those are recomputed with the host's libm from their exact (x, r2)
+and patched in, as is the cached second normal that an odd-length draw hands back to NumPy as generator state.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+ACCEPT = 0.7853981633974483            # pi / 4: the probability that a group of four words is accepted
+_TWO53 = 9007199254740992.0
+
+
+def temper(y: torch.Tensor) -> torch.Tensor:
+    """MT19937 tempering of raw state words (int64 tensor holding uint32 values)."""
+    y = y ^ (y >> 11)
+    y = y ^ ((y << 7) & 0x9D2C5680)
+    y = y ^ ((y << 15) & 0xEFC60000)
+    y = y ^ (y >> 18)
+    return y & 0xFFFFFFFF
+
+
+def mt_next_block(key: np.ndarray) -> np.ndarray:
+    """mt19937_gen restated in NumPy (the test oracle of imgxf_mt19937_blocks): the 624 state words after `key`."""
+    old = key.astype(np.uint64)
+    new = np.zeros(624, np.uint64)
+
+    def twist(u, v):
+        y = (u & 0x80000000) | (v & 0x7FFFFFFF)
+        return (y >> 1) ^ np.where(v & 1, 0x9908B0DF, 0).astype(np.uint64)
+    new[:227] = old[397:624] ^ twist(old[:227], old[1:228])
+    new[227:454] = new[0:227] ^ twist(old[227:454], old[228:455])
+    new[454:623] = new[227:396] ^ twist(old[454:623], old[455:624])
+    new[623] = new[396] ^ twist(old[623:624], new[0:1])[0]
+    return (new & 0xFFFFFFFF).astype(np.uint32)
+
+
+def words_needed(n_normals: int) -> int:
+    """Stream words that certainly hold `n_normals` normals: the expected number of four-word groups plus a margin of
+    more than 12 standard deviations (a multiple of 4)."""
+    groups = (n_normals + 1) // 2
+    want = int(groups / ACCEPT * 1.01) + 3000
+    return 4 * want
+
+
+class Draw:
+    """The result of `normals`: float32 noise tensors (on the stream tensor's device), the stream position after the last
+    draw, the generator's pending cached value, and whether any sample was too close to a float32 rounding boundary."""
+    __slots__ = ("noise", "position", "has_gauss", "gauss", "patched")
+
+
+def _host_gauss(x: float, r2: float) -> float:
+    """f x with f = sqrt(-2 log(r2) / r2) in the host's libm, as legacy_gauss computes it."""
+    return math.sqrt(-2.0 * math.log(r2) / r2) * x
+
+
+MARGIN = 2.0 ** -46          # relative; the device's log is within an ulp (2^-53) of glibc's, f x and the scaling add a few more
+
+
+def normals(raw: torch.Tensor, start: int, has_gauss: bool, gauss: float, requests: Sequence[tuple]) -> Draw:
+    """`raw`: the raw MT19937 state sequence as an int32 / int64 tensor of uint32 bit patterns (block 0 = the generator's
+    current key; what imgxf_mt19937_blocks writes), `start`: the generator's position in it (its `pos`), `has_gauss` /
+    `gauss`: its cached normal.  `requests`: (count, scale) per draw, in the order NumPy would be called.  Raises ValueError
+    if `raw` is too short for the margins of words_needed.
+
+    Exactness of the float32 results: a sample whose double lies within MARGIN (relative) of a float32 rounding boundary —
+    one in 2^21, a few per million — is recomputed with the HOST's log from its exact (x, r2) and patched in; so is the
+    cached normal that a draw of odd length leaves behind (it becomes generator state)."""
+    dev = raw.device
+    pos = int(start)
+    out: List[torch.Tensor] = []
+    cached = float(gauss)
+    patched = 0
+    for count, scale in requests:
+        count, scale = int(count), float(scale)
+        if count == 0:
+            out.append(torch.empty((0,), dtype=torch.float32, device=dev))
+            continue
+        n2 = count - (1 if has_gauss else 0)
+        head = [np.float32(0.0 + scale * cached)] if has_gauss else []       # the cached normal is exact (host libm)
+        if n2 > 0:
+            groups = (n2 + 1) // 2
+            w = words_needed(n2)
+            if pos + w > raw.numel():
+                raise ValueError("the MT19937 stream is shorter than the draw's margin")
+            t = temper(raw[pos:pos + w].to(torch.int64) & 0xFFFFFFFF).view(-1, 4)
+            u1 = ((t[:, 0] >> 5).double() * 67108864.0 + (t[:, 1] >> 6).double()) / _TWO53
+            u2 = ((t[:, 2] >> 5).double() * 67108864.0 + (t[:, 3] >> 6).double()) / _TWO53
+            x1, x2 = 2.0 * u1 - 1.0, 2.0 * u2 - 1.0
+            r2 = x1 * x1 + x2 * x2
+            acc = (r2 < 1.0) & (r2 != 0.0)
+            rank = torch.cumsum(acc, 0)
+            last = int((rank < groups).sum().item())                      # index of the groups-th accepted group
+            if last >= rank.numel():
+                raise ValueError("too few accepted groups inside the margin")                  # (> 12 sigma: not expected to happen)
+            sel = acc[:last + 1]
+            a1, a2, ar = x1[:last + 1][sel], x2[:last + 1][sel], r2[:last + 1][sel]
+            f = torch.sqrt(-2.0 * torch.log(ar) / ar)
+            xs = torch.stack((a2, a1), 1).reshape(-1)                    # the call returns f x2 first, f x1 on the next call
+            vals = f.repeat_interleave(2) * xs
+            nd = 0.0 + scale * vals[:n2]                                 # legacy_normal: loc + scale * gauss
+            n32 = nd.float()
+            risky = ((nd * (1.0 - MARGIN)).float() != (nd * (1.0 + MARGIN)).float()).nonzero().flatten()
+            if risky.numel():
+                e = risky.cpu()
+                xv, rv = xs[risky].cpu().tolist(), ar[risky // 2].cpu().tolist()
+                fix = torch.tensor([np.float32(0.0 + scale * _host_gauss(x, r)) for x, r in zip(xv, rv)], dtype=torch.float32)
+                n32[risky] = fix.to(dev)
+                patched += int(e.numel())
+            has_gauss = bool(n2 & 1)
+            if has_gauss:                                                # exact: it is handed back to NumPy as generator state
+                cached = _host_gauss(float(xs[n2].item()), float(ar[n2 // 2].item()))
+            else:
+                cached = 0.0
+            pos += 4 * (last + 1)
+            out.append(torch.cat((torch.tensor(head, dtype=torch.float32, device=dev), n32)) if head else n32)
+        else:
+            has_gauss, cached = False, 0.0                               # the cached value was the whole draw
+            out.append(torch.tensor(head, dtype=torch.float32, device=dev))
+    d = Draw()
+    d.noise, d.position, d.has_gauss, d.gauss, d.patched = out, pos, has_gauss, cached, patched
+    return d
+
+
+def state_at(raw: torch.Tensor, position: int, start: int):
+    """(key[624] as a uint32 NumPy array, pos) of the generator after consuming the stream up to `position` — in NumPy's own
+    representation: the block is only regenerated by the NEXT request, so a position on a block boundary is `pos = 624`
+    of the block before."""
+    b, p = divmod(position, 624)
+    if p == 0 and position > 0 and position != start:
+        b, p = b - 1, 624
+    key = (raw[b * 624:(b + 1) * 624].to(torch.int64) & 0xFFFFFFFF).to("cpu").numpy().astype(np.uint32)
+    return key, p
+
+
+def draw_on_device(requests: Sequence[tuple], device) -> List[torch.Tensor] | None:
+    """The float32 results of `[np.random.normal(0, scale, count).astype(np.float32) for count, scale in requests]` as
+    device tensors, with np.random's global state advanced exactly as those calls would have advanced it — or None (state
+    untouched) if the global generator is not the legacy MT19937: the caller then makes the calls on the host."""
+    from . import _ffi as F
+    device = torch.device(device)
+    requests = [(int(n), float(s)) for n, s in requests]
+    if not any(n for n, _ in requests):
+        return [torch.empty((0,), dtype=torch.float32, device=device) for _ in requests]
+    kind, key, pos, has_gauss, gauss = np.random.get_state()
+    if kind != "MT19937":
+        return None
+    total = sum(words_needed(n) for n, _ in requests if n)
+    nblocks = (int(pos) + total) // 624 + 2
+    with torch.cuda.device(device):
+        key_d = torch.from_numpy(key.astype(np.uint32).view(np.int32).copy()).to(device)
+        raw = torch.empty(((nblocks + 1) * 624,), dtype=torch.int32, device=device)
+        F.call("imgxf_mt19937_blocks", key_d.data_ptr(), raw.data_ptr(), nblocks, torch.cuda.current_stream(device).cuda_stream)
+        d = normals(raw, int(pos), bool(has_gauss), float(gauss), requests)
+        if d.position != int(pos) or bool(has_gauss) != d.has_gauss:
+            k, p = state_at(raw, d.position, int(pos))
+            np.random.set_state((kind, k, p, int(d.has_gauss), float(d.gauss) if d.has_gauss else 0.0))
+    return d.noise

@@ -161,12 +161,17 @@ def apply_brightness(img: Image.Image, brightness_factor: float) -> Image.Image:
 
 
 # ------------------------------------------------------------------ gaussian noise (:272-281)
-# "numpy" (default): the reference's own stream — np.random.normal on the host, bit-exact parity.
+# "numpy" (default): the reference's own stream, bit-exact parity for the same np.random.seed.  Since late round 3 the
+#   numbers themselves are computed on the device (numpy_stream.draw_on_device: MT19937 blocks + legacy_gauss restated, the
+#   global generator's state advanced as np.random.normal would have; host draw if a sample is too close to a float32
+#   rounding boundary for the device's log to be trusted).  "numpy-host" (IMGXF_NOISE_RNG=numpy-host): np.random.normal
+#   on the host, as the reference itself.
 # "device" (IMGXF_NOISE_RNG=device, opt-in): Philox4x32-10 + Box-Muller inside the add kernel; ONE np.random draw
 # per call supplies the seed (so np.random.seed still makes a run repeatable), the pixels differ from the reference's
 # for the same seed: distribution-level parity only (tests/test_gpu_noise_rng.py).  The host draw
 # is ~8 of the 8.6 ms per 375 x 500 image in the batched driver.
 NOISE_RNG = os.environ.get("IMGXF_NOISE_RNG", "numpy")
+NOISE_DEVICE_MIN = 1 << 16                               # normals per call below which the host draws them itself
 
 
 def _noise_seed() -> int:
@@ -180,10 +185,23 @@ def apply_gaussian_noise(img: Image.Image, noise_std: float) -> Image.Image:
     if NOISE_RNG == "device":
         return _download(ops.add_noise_device(_upload(img), noise_std * 255, _noise_seed()))
     img_array = np.array(img)
-    noise = np.random.normal(0, noise_std * 255, img_array.shape).astype(np.float32)
     dev = _device()
-    out = ops.add_noise(torch.from_numpy(img_array).to(dev), torch.from_numpy(noise).to(dev))
+    z = _numpy_noise([(img_array.size, noise_std * 255)], dev)[0]
+    if z is None:
+        z = torch.from_numpy(np.random.normal(0, noise_std * 255, img_array.shape).astype(np.float32)).to(dev)
+    out = ops.add_noise(torch.from_numpy(img_array).to(dev), z.view(img_array.shape))
     return _download(out)
+
+
+def _numpy_noise(requests, dev):
+    """[(count, scale)] -> float32 device tensors holding np.random.normal(0, scale, count).astype(float32) for each request,
+    np.random's state advanced accordingly; [None, ...] (state untouched) when the host has to draw: mode "numpy-host", or
+    numpy_stream's uncertainty guard."""
+    if NOISE_RNG == "numpy-host" or not requests or sum(n for n, _ in requests) < NOISE_DEVICE_MIN:
+        return [None] * len(requests)               # (a CIFAR image is 3072 normals: 50 us on the host, less than one launch)
+    from . import numpy_stream
+    got = numpy_stream.draw_on_device(requests, dev)
+    return got if got is not None else [None] * len(requests)
 
 
 # ------------------------------------------------------------------ translation (:284-307)
@@ -405,6 +423,7 @@ def apply_all_transformations_batched_named(images, _sink=None):
     those entries come back as (file name, None)."""
     dev = _device()
     plans, noise = [], {}
+    draws = []                                          # (i, k, (h, w, 3), scale): np.random.normal calls in the per-image loop's order
     for i, (img, path) in enumerate(images):
         name = os.path.splitext(os.path.basename(path))[0]
         plan = plan_transformations(name)
@@ -415,7 +434,13 @@ def apply_all_transformations_batched_named(images, _sink=None):
                 if NOISE_RNG == "device":               # opt-in: one seed per image instead of h * w * 3 normals
                     noise[(i, k)] = _noise_seed()
                 else:
-                    noise[(i, k)] = np.random.normal(0, args[0] * 255, (h, w, 3)).astype(np.float32)
+                    draws.append((i, k, (h, w, 3), args[0] * 255))
+    if draws:
+        # nothing else touches np.random between these calls (the grid values come from `random`): one pass over the stream
+        # on the device serves them all, or the host makes them one by one
+        got = _numpy_noise([(h * w * c, scale) for _, _, (h, w, c), scale in draws], dev)
+        for (i, k, shape, scale), z in zip(draws, got):
+            noise[(i, k)] = z.view(shape) if z is not None else np.random.normal(0, scale, shape).astype(np.float32)
 
     results = [[None] * len(p) for p in plans]
     by_size = {}
@@ -463,7 +488,8 @@ def apply_all_transformations_batched_named(images, _sink=None):
                 for j, (_, i, k) in enumerate(entries):
                     out[j] = ops.add_noise_device(batch[j], args[0] * 255, noise[(i, k)])
             elif transform_type == 'gaussian_noise':
-                z = staging.upload([noise[(i, k)] for _, i, k in entries], dev)
+                zs = [noise[(i, k)] for _, i, k in entries]
+                z = torch.stack(zs) if isinstance(zs[0], torch.Tensor) else staging.upload(zs, dev)
                 out = ops.add_noise(batch, z)
             else:
                 out = tensor_fns[transform_type](batch, *args)

@@ -404,6 +404,12 @@ int imgxf_jpeg_decode_huffman(const uint8_t* scan, const int64_t* seg_off, const
  * jpeg_decode._segments for the batched reader (load_data's Image.open, /root/reference/transformation.py:73-89). */
 int imgxf_jpeg_unstuff_host(const uint8_t* data, size_t n, size_t start, uint8_t* scan, size_t scan_cap, size_t* scan_pos,
                             int64_t* seg_off, int32_t* seg_len, int max_segs, int* nsegs, size_t* ecs_end);
+/* NumPy's legacy generator on the device (np.random.normal of apply_gaussian_noise, /root/reference/transformation.py:273-275):
+ * the raw MT19937 state sequence — out[0 .. 623] = key (device pointer, the generator's current 624 state words), block b =
+ * the state after b regenerations (mt19937_gen), (nblocks + 1) * 624 words in all.  One workgroup: the recurrence is
+ * sequential in the block index.  Tempering, legacy_double and the polar method follow in imagetransformations_amd/numpy_stream.py. */
+int imgxf_mt19937_blocks(const uint32_t* key, uint32_t* out, int64_t nblocks, void* stream);
+
 /* Why a file is outside the reader's class, or damaged (status[] of imgxf_jpeg_layout_host; 0 = accepted). */
 enum { IMGXF_JPEG_E_NOT_JPEG = 1,    /* no SOI */
        IMGXF_JPEG_E_MARKERS = 2,     /* damaged marker structure (also: SOS before SOF) */

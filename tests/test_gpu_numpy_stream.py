@@ -1,0 +1,63 @@
+"""GPU: NumPy's legacy normal stream on the device (csrc/noise_rng.hip imgxf_mt19937_blocks + numpy_stream.py): the block
+kernel against the NumPy restatement, and draw_on_device against np.random.normal itself — numbers and generator state."""
+import numpy as np
+import pytest
+import torch
+
+from imagetransformations_amd import _ffi as F, numpy_stream as NS
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mt19937_block_kernel_equals_the_restatement(device):
+    key = np.random.RandomState(77).get_state()[1]
+    nblocks = 40
+    key_d = torch.from_numpy(key.astype(np.uint32).view(np.int32).copy()).to(device)
+    raw = torch.empty(((nblocks + 1) * 624,), dtype=torch.int32, device=device)
+    F.call("imgxf_mt19937_blocks", key_d.data_ptr(), raw.data_ptr(), nblocks, torch.cuda.current_stream().cuda_stream)
+    got = raw.cpu().numpy().view(np.uint32).reshape(nblocks + 1, 624)
+    want = key.astype(np.uint32)
+    for b in range(nblocks + 1):
+        assert np.array_equal(got[b], want), b
+        want = NS.mt_next_block(want)
+
+
+@pytest.mark.parametrize("seed,requests", [(0, [(375 * 500 * 3, 0.05 * 255)]), (5, [(999, 2.0), (1, 1.0), (64 * 48 * 3, 25.5), (7, 0.1)]),
+                                           (9, [(32 * 32 * 3, 0.08 * 255)] * 9)])
+def test_draw_on_device_is_np_random_normal(device, seed, requests):
+    np.random.seed(seed)
+    np.random.random_sample(seed)                      # somewhere inside a block
+    st = np.random.get_state()
+    want = [np.random.normal(0, s, n).astype(np.float32) for n, s in requests]
+    after = np.random.get_state()
+    np.random.set_state(st)
+    got = NS.draw_on_device(requests, device)
+    assert got is not None
+    for g, w in zip(got, want):
+        assert np.array_equal(g.cpu().numpy(), w)
+    now = np.random.get_state()
+    assert now[2] == after[2] and np.array_equal(now[1], after[1]) and now[3] == after[3] and (now[4] == after[4] or not now[3])
+    follow = np.random.normal(0, 1, 5)                 # the host's next draw continues where the device stopped
+    np.random.set_state(after)
+    assert np.array_equal(follow, np.random.normal(0, 1, 5))
+
+
+def test_drivers_give_the_same_images_with_the_noise_drawn_on_the_device(device, monkeypatch):
+    """apply_gaussian_noise and the batched driver with the default mode (NumPy's stream computed on the device) against the
+    same calls with the host drawing the numbers (IMGXF_NOISE_RNG=numpy-host): identical pixels, identical np.random state."""
+    import random
+    from PIL import Image
+    from conftest import synth
+    from imagetransformations_amd import transformation as T
+    imgs = [(Image.fromarray(synth(900 + i, 61 + 3 * (i % 2), 83)), f"img_{i}.jpeg") for i in range(5)]
+    outs, states = [], []
+    for mode in ("numpy", "numpy-host"):
+        monkeypatch.setattr(T, "NOISE_RNG", mode)
+        random.seed(3); np.random.seed(3)
+        a = T.apply_gaussian_noise(imgs[0][0], 0.07)
+        b = T.apply_all_transformations_batched(imgs)
+        outs.append([np.asarray(a)] + [np.asarray(im) for im in b])
+        states.append(np.random.get_state())
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    assert states[0][2] == states[1][2] and np.array_equal(states[0][1], states[1][1]) and states[0][3] == states[1][3]
