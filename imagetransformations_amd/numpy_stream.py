@@ -78,7 +78,7 @@ def _host_gauss(x: float, r2: float) -> float:
 MARGIN = 2.0 ** -46          # relative; the device's log is within an ulp (2^-53) of glibc's, f x and the scaling add a few more
 
 
-def normals(raw: torch.Tensor, start: int, has_gauss: bool, gauss: float, requests: Sequence[tuple]) -> Draw:
+def normals(raw: torch.Tensor, start: int, has_gauss: bool, gauss: float, requests: Sequence[tuple], f64: bool = False) -> Draw:
     """`raw`: the raw MT19937 state sequence as an int32 / int64 tensor of uint32 bit patterns (block 0 = the generator's
     current key; what imgxf_mt19937_blocks writes), `start`: the generator's position in it (its `pos`), `has_gauss` /
     `gauss`: its cached normal.  `requests`: (count, scale) per draw, in the order NumPy would be called.  Raises ValueError
@@ -86,7 +86,10 @@ def normals(raw: torch.Tensor, start: int, has_gauss: bool, gauss: float, reques
 
     Exactness of the float32 results: a sample whose double lies within MARGIN (relative) of a float32 rounding boundary —
     one in 2^21, a few per million — is recomputed with the HOST's log from its exact (x, r2) and patched in; so is the
-    cached normal that a draw of odd length leaves behind (it becomes generator state)."""
+    cached normal that a draw of odd length leaves behind (it becomes generator state).
+    `f64=True` returns the DOUBLES (TransformationPool.gaussian_noise adds them to the float32 image in double and truncates,
+    cifar_image_transformations.py:39-48): a pixel's byte can only depend on the last bits of the double when the noise is
+    within 1e-9 of an integer; those samples take the host path instead."""
     dev = raw.device
     pos = int(start)
     out: List[torch.Tensor] = []
@@ -95,10 +98,11 @@ def normals(raw: torch.Tensor, start: int, has_gauss: bool, gauss: float, reques
     for count, scale in requests:
         count, scale = int(count), float(scale)
         if count == 0:
-            out.append(torch.empty((0,), dtype=torch.float32, device=dev))
+            out.append(torch.empty((0,), dtype=torch.float64 if f64 else torch.float32, device=dev))
             continue
         n2 = count - (1 if has_gauss else 0)
-        head = [np.float32(0.0 + scale * cached)] if has_gauss else []       # the cached normal is exact (host libm)
+        head = [(0.0 + scale * cached) if f64 else np.float32(0.0 + scale * cached)] if has_gauss else []    # the cached normal is exact (host libm)
+        odt = torch.float64 if f64 else torch.float32
         if n2 > 0:
             groups = (n2 + 1) // 2
             w = words_needed(n2)
@@ -120,24 +124,27 @@ def normals(raw: torch.Tensor, start: int, has_gauss: bool, gauss: float, reques
             xs = torch.stack((a2, a1), 1).reshape(-1)                    # the call returns f x2 first, f x1 on the next call
             vals = f.repeat_interleave(2) * xs
             nd = 0.0 + scale * vals[:n2]                                 # legacy_normal: loc + scale * gauss
-            n32 = nd.float()
-            risky = ((nd * (1.0 - MARGIN)).float() != (nd * (1.0 + MARGIN)).float()).nonzero().flatten()
+            if f64:
+                n32 = nd.clone()
+                risky = ((nd - torch.round(nd)).abs() < 1e-9).nonzero().flatten()
+            else:
+                n32 = nd.float()
+                risky = ((nd * (1.0 - MARGIN)).float() != (nd * (1.0 + MARGIN)).float()).nonzero().flatten()
             if risky.numel():
-                e = risky.cpu()
                 xv, rv = xs[risky].cpu().tolist(), ar[risky // 2].cpu().tolist()
-                fix = torch.tensor([np.float32(0.0 + scale * _host_gauss(x, r)) for x, r in zip(xv, rv)], dtype=torch.float32)
-                n32[risky] = fix.to(dev)
-                patched += int(e.numel())
+                exact = [0.0 + scale * _host_gauss(x, r) for x, r in zip(xv, rv)]
+                n32[risky] = torch.tensor(exact if f64 else [np.float32(v) for v in exact], dtype=odt).to(dev)
+                patched += int(risky.numel())
             has_gauss = bool(n2 & 1)
             if has_gauss:                                                # exact: it is handed back to NumPy as generator state
                 cached = _host_gauss(float(xs[n2].item()), float(ar[n2 // 2].item()))
             else:
                 cached = 0.0
             pos += 4 * (last + 1)
-            out.append(torch.cat((torch.tensor(head, dtype=torch.float32, device=dev), n32)) if head else n32)
+            out.append(torch.cat((torch.tensor(head, dtype=odt, device=dev), n32)) if head else n32)
         else:
             has_gauss, cached = False, 0.0                               # the cached value was the whole draw
-            out.append(torch.tensor(head, dtype=torch.float32, device=dev))
+            out.append(torch.tensor(head, dtype=odt, device=dev))
     d = Draw()
     d.noise, d.position, d.has_gauss, d.gauss, d.patched = out, pos, has_gauss, cached, patched
     return d
@@ -154,7 +161,7 @@ def state_at(raw: torch.Tensor, position: int, start: int):
     return key, p
 
 
-def draw_on_device(requests: Sequence[tuple], device) -> List[torch.Tensor] | None:
+def draw_on_device(requests: Sequence[tuple], device, f64: bool = False) -> List[torch.Tensor] | None:
     """The float32 results of `[np.random.normal(0, scale, count).astype(np.float32) for count, scale in requests]` as
     device tensors, with np.random's global state advanced exactly as those calls would have advanced it — or None (state
     untouched) if the global generator is not the legacy MT19937: the caller then makes the calls on the host."""
@@ -162,7 +169,7 @@ def draw_on_device(requests: Sequence[tuple], device) -> List[torch.Tensor] | No
     device = torch.device(device)
     requests = [(int(n), float(s)) for n, s in requests]
     if not any(n for n, _ in requests):
-        return [torch.empty((0,), dtype=torch.float32, device=device) for _ in requests]
+        return [torch.empty((0,), dtype=torch.float64 if f64 else torch.float32, device=device) for _ in requests]
     kind, key, pos, has_gauss, gauss = np.random.get_state()
     if kind != "MT19937":
         return None
@@ -172,7 +179,7 @@ def draw_on_device(requests: Sequence[tuple], device) -> List[torch.Tensor] | No
         key_d = torch.from_numpy(key.astype(np.uint32).view(np.int32).copy()).to(device)
         raw = torch.empty(((nblocks + 1) * 624,), dtype=torch.int32, device=device)
         F.call("imgxf_mt19937_blocks", key_d.data_ptr(), raw.data_ptr(), nblocks, torch.cuda.current_stream(device).cuda_stream)
-        d = normals(raw, int(pos), bool(has_gauss), float(gauss), requests)
+        d = normals(raw, int(pos), bool(has_gauss), float(gauss), requests, f64)
         if d.position != int(pos) or bool(has_gauss) != d.has_gauss:
             k, p = state_at(raw, d.position, int(pos))
             np.random.set_state((kind, k, p, int(d.has_gauss), float(d.gauss) if d.has_gauss else 0.0))

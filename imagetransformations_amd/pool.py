@@ -13,7 +13,7 @@ from PIL import Image
 
 import torch
 
-from . import ops
+from . import ops, transformation as T
 from .transformation import _device, _download, _upload
 
 
@@ -26,15 +26,22 @@ class TransformationPool:
         return _download(ops.yuv2rgb(ops.equalize_hist_cv(ops.rgb2yuv(t), 0)))
 
     def gaussian_noise(image, severity=None):
-        """cifar_image_transformations.py:39-48.  Noise drawn on the host from np.random (same
-        stream as the reference for the same seed), added and clipped on the device in float64."""
+        """cifar_image_transformations.py:39-48.  np.random's own stream for the same seed (computed on the device for
+        images of at least NOISE_DEVICE_MIN samples, numpy_stream.py; drawn on the host below that), added and clipped on
+        the device in float64."""
         if severity is None:
             severity = random.choice([1, 2, 3, 4, 5])
         img_array = np.array(image)
         noise_std = [0.08, 0.12, 0.18, 0.26, 0.38][severity - 1]
-        noise = np.random.normal(0, noise_std * 255, img_array.shape)
         dev = _device()
-        return _download(ops.add_noise_f64(torch.from_numpy(img_array).to(dev), torch.from_numpy(noise).to(dev)))
+        z = None
+        if T.NOISE_RNG != "numpy-host" and img_array.size >= T.NOISE_DEVICE_MIN:    # the same doubles, computed on the device
+            from . import numpy_stream
+            got = numpy_stream.draw_on_device([(img_array.size, noise_std * 255)], dev, f64=True)
+            z = got[0].view(img_array.shape) if got is not None else None
+        if z is None:
+            z = torch.from_numpy(np.random.normal(0, noise_std * 255, img_array.shape)).to(dev)
+        return _download(ops.add_noise_f64(torch.from_numpy(img_array).to(dev), z))
 
     def impulse_noise(image, severity=None):
         """cifar_image_transformations.py:50-59."""

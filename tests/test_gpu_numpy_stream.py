@@ -61,3 +61,24 @@ def test_drivers_give_the_same_images_with_the_noise_drawn_on_the_device(device,
     for x, y in zip(*outs):
         assert np.array_equal(x, y)
     assert states[0][2] == states[1][2] and np.array_equal(states[0][1], states[1][1]) and states[0][3] == states[1][3]
+
+
+def test_pool_gaussian_noise_doubles_on_the_device(device, monkeypatch):
+    """TransformationPool.gaussian_noise adds float64 noise (cifar_image_transformations.py:39-48): the device-computed doubles
+    give the pixels of the host draw and leave np.random where it would be, for an ImageNet-size image (CIFAR sizes stay on
+    the host)."""
+    from PIL import Image
+    from conftest import synth
+    from imagetransformations_amd import transformation as T
+    from imagetransformations_amd.pool import TransformationPool as P
+    img = Image.fromarray(synth(950, 180, 240))
+    res = []
+    for mode in ("numpy", "numpy-host"):
+        monkeypatch.setattr(T, "NOISE_RNG", mode)
+        np.random.seed(17)
+        a = np.asarray(P.gaussian_noise(img, 3))
+        b = np.asarray(P.gaussian_noise(img, 5))
+        res.append((a, b, np.random.get_state()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    s0, s1 = res[0][2], res[1][2]
+    assert s0[2] == s1[2] and np.array_equal(s0[1], s1[1]) and s0[3] == s1[3] and (s0[4] == s1[4] or not s0[3])
