@@ -97,24 +97,33 @@ __global__ __launch_bounds__(256) void mt19937_blocks_kernel(const u32* __restri
     for (int i = tid; i < 624; i += 256) { const u32 v = key[i]; st[0][i] = v; out[i] = v; }
     __syncthreads();
     auto twist = [](u32 u, u32 v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); };
-    // barriers that wait for the LDS traffic only: __syncthreads() also drains the global stores of the previous block
-    // (2.5 us per block with it, measured)
-#define IMGXF_MT_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // Inside a block, thread t computes new[t], new[227 + t] (from its own new[t]) and new[454 + t] (from its own new[227 + t]):
+    // the distance of the recurrence is 227, so the chain stays in the thread's registers.  Only new[623] needs other
+    // threads' words (new[396] and new[0]); thread 0 recomputes new[396] from the old block itself.  ONE barrier per block —
+    // the next block reads everybody's words — and it waits for the LDS traffic only (__syncthreads() would also drain the
+    // global stores: 535 ns per block with four of those).
     for (long long b = 1; b <= nblocks; ++b) {
         const u32* o = st[(b - 1) & 1];
         u32* n = st[b & 1];
-        if (tid < 227) n[tid] = o[tid + 397] ^ twist(o[tid], o[tid + 1]);
-        IMGXF_MT_BAR();
-        if (tid < 227) n[227 + tid] = n[tid] ^ twist(o[227 + tid], o[228 + tid]);
-        IMGXF_MT_BAR();
-        if (tid < 169) n[454 + tid] = n[227 + tid] ^ twist(o[454 + tid], o[455 + tid]);
-        IMGXF_MT_BAR();
-        if (tid == 0) n[623] = n[396] ^ twist(o[623], n[0]);
-        IMGXF_MT_BAR();
         u32* dst = out + b * 624;
-        for (int i = tid; i < 624; i += 256) dst[i] = n[i];
+        if (tid < 227) {
+            const u32 a = o[tid + 397] ^ twist(o[tid], o[tid + 1]);
+            const u32 c = a ^ twist(o[227 + tid], o[228 + tid]);
+            n[tid] = a; n[227 + tid] = c;
+            dst[tid] = a; dst[227 + tid] = c;
+            if (tid < 169) {
+                const u32 e = c ^ twist(o[454 + tid], o[455 + tid]);
+                n[454 + tid] = e; dst[454 + tid] = e;
+            }
+            if (tid == 0) {
+                const u32 n169 = o[566] ^ twist(o[169], o[170]);
+                const u32 n396 = n169 ^ twist(o[396], o[397]);
+                const u32 z = n396 ^ twist(o[623], a);
+                n[623] = z; dst[623] = z;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-#undef IMGXF_MT_BAR
 }
 } // namespace imgxf
 
