@@ -82,70 +82,93 @@ def normals(raw: torch.Tensor, start: int, has_gauss: bool, gauss: float, reques
     """`raw`: the raw MT19937 state sequence as an int32 / int64 tensor of uint32 bit patterns (block 0 = the generator's
     current key; what imgxf_mt19937_blocks writes), `start`: the generator's position in it (its `pos`), `has_gauss` /
     `gauss`: its cached normal.  `requests`: (count, scale) per draw, in the order NumPy would be called.  Raises ValueError
-    if `raw` is too short for the margins of words_needed.
+    if `raw` is too short for the margin of words_needed.
+
+    legacy_gauss is a STREAM of normals — the pairs of the accepted groups in order, a cached value being the second of a
+    pair — and consecutive np.random.normal calls just take consecutive stretches of it: all requests are served by ONE pass
+    over the words (no per-request synchronisation), then cut at the known counts and scaled.
 
     Exactness of the float32 results: a sample whose double lies within MARGIN (relative) of a float32 rounding boundary —
     one in 2^21, a few per million — is recomputed with the HOST's log from its exact (x, r2) and patched in; so is the
-    cached normal that a draw of odd length leaves behind (it becomes generator state).
+    cached normal that an odd number of normals leaves behind (it becomes generator state).
     `f64=True` returns the DOUBLES (TransformationPool.gaussian_noise adds them to the float32 image in double and truncates,
     cifar_image_transformations.py:39-48): a pixel's byte can only depend on the last bits of the double when the noise is
     within 1e-9 of an integer; those samples take the host path instead."""
     dev = raw.device
     pos = int(start)
+    odt = torch.float64 if f64 else torch.float32
+    counts = [int(n) for n, _ in requests]
+    total = sum(counts)
+    d = Draw()
+    if total == 0:
+        d.noise = [torch.empty((0,), dtype=odt, device=dev) for _ in requests]
+        d.position, d.has_gauss, d.gauss, d.patched = pos, has_gauss, float(gauss), 0
+        return d
+    n2 = total - (1 if has_gauss else 0)                     # normals to take from new groups
+    xs = ar = None
+    if n2 > 0:
+        groups = (n2 + 1) // 2
+        w = words_needed(n2)
+        if pos + w > raw.numel():
+            raise ValueError("the MT19937 stream is shorter than the draw's margin")
+        t = temper(raw[pos:pos + w].to(torch.int64) & 0xFFFFFFFF).view(-1, 4)
+        u1 = ((t[:, 0] >> 5).double() * 67108864.0 + (t[:, 1] >> 6).double()) / _TWO53
+        u2 = ((t[:, 2] >> 5).double() * 67108864.0 + (t[:, 3] >> 6).double()) / _TWO53
+        del t
+        x1, x2 = 2.0 * u1 - 1.0, 2.0 * u2 - 1.0
+        del u1, u2
+        r2 = x1 * x1 + x2 * x2
+        acc = (r2 < 1.0) & (r2 != 0.0)
+        rank = torch.cumsum(acc, 0)
+        last = int((rank < groups).sum().item())             # index of the groups-th accepted group
+        if last >= rank.numel():
+            raise ValueError("too few accepted groups inside the margin")                      # (> 12 sigma: not expected to happen)
+        del rank
+        sel = acc[:last + 1]
+        a1, a2, ar = x1[:last + 1][sel], x2[:last + 1][sel], r2[:last + 1][sel]
+        del x1, x2, r2, acc, sel
+        f = torch.sqrt(-2.0 * torch.log(ar) / ar)
+        xs = torch.stack((a2, a1), 1).reshape(-1)            # the call returns f x2 first, f x1 on the next call
+        del a1, a2
+        vals = (f.repeat_interleave(2) * xs)[:n2]
+        del f
+        pos += 4 * (last + 1)
+    # the stream the requests cut up: [cached normal (exact, host libm)] + vals; sample e of vals is (xs[e], ar[e // 2])
+    lead = 1 if has_gauss else 0
     out: List[torch.Tensor] = []
-    cached = float(gauss)
-    patched = 0
+    patched, at = 0, 0
     for count, scale in requests:
         count, scale = int(count), float(scale)
         if count == 0:
-            out.append(torch.empty((0,), dtype=torch.float64 if f64 else torch.float32, device=dev))
+            out.append(torch.empty((0,), dtype=odt, device=dev))
             continue
-        n2 = count - (1 if has_gauss else 0)
-        head = [(0.0 + scale * cached) if f64 else np.float32(0.0 + scale * cached)] if has_gauss else []    # the cached normal is exact (host libm)
-        odt = torch.float64 if f64 else torch.float32
-        if n2 > 0:
-            groups = (n2 + 1) // 2
-            w = words_needed(n2)
-            if pos + w > raw.numel():
-                raise ValueError("the MT19937 stream is shorter than the draw's margin")
-            t = temper(raw[pos:pos + w].to(torch.int64) & 0xFFFFFFFF).view(-1, 4)
-            u1 = ((t[:, 0] >> 5).double() * 67108864.0 + (t[:, 1] >> 6).double()) / _TWO53
-            u2 = ((t[:, 2] >> 5).double() * 67108864.0 + (t[:, 3] >> 6).double()) / _TWO53
-            x1, x2 = 2.0 * u1 - 1.0, 2.0 * u2 - 1.0
-            r2 = x1 * x1 + x2 * x2
-            acc = (r2 < 1.0) & (r2 != 0.0)
-            rank = torch.cumsum(acc, 0)
-            last = int((rank < groups).sum().item())                      # index of the groups-th accepted group
-            if last >= rank.numel():
-                raise ValueError("too few accepted groups inside the margin")                  # (> 12 sigma: not expected to happen)
-            sel = acc[:last + 1]
-            a1, a2, ar = x1[:last + 1][sel], x2[:last + 1][sel], r2[:last + 1][sel]
-            f = torch.sqrt(-2.0 * torch.log(ar) / ar)
-            xs = torch.stack((a2, a1), 1).reshape(-1)                    # the call returns f x2 first, f x1 on the next call
-            vals = f.repeat_interleave(2) * xs
-            nd = 0.0 + scale * vals[:n2]                                 # legacy_normal: loc + scale * gauss
+        lo, hi = at - lead, at + count - lead                # range in vals (lo = -1: the cached normal comes first)
+        head = []
+        if lo < 0:
+            v = 0.0 + scale * float(gauss)
+            head, lo = [v if f64 else np.float32(v)], 0
+        if hi > lo:
+            nd = 0.0 + scale * vals[lo:hi]                   # legacy_normal: loc + scale * gauss
             if f64:
-                n32 = nd.clone()
+                res = nd
                 risky = ((nd - torch.round(nd)).abs() < 1e-9).nonzero().flatten()
             else:
-                n32 = nd.float()
+                res = nd.float()
                 risky = ((nd * (1.0 - MARGIN)).float() != (nd * (1.0 + MARGIN)).float()).nonzero().flatten()
             if risky.numel():
-                xv, rv = xs[risky].cpu().tolist(), ar[risky // 2].cpu().tolist()
+                e = risky + lo
+                xv, rv = xs[e].cpu().tolist(), ar[e // 2].cpu().tolist()
                 exact = [0.0 + scale * _host_gauss(x, r) for x, r in zip(xv, rv)]
-                n32[risky] = torch.tensor(exact if f64 else [np.float32(v) for v in exact], dtype=odt).to(dev)
+                res[risky] = torch.tensor(exact if f64 else [np.float32(v) for v in exact], dtype=odt).to(dev)
                 patched += int(risky.numel())
-            has_gauss = bool(n2 & 1)
-            if has_gauss:                                                # exact: it is handed back to NumPy as generator state
-                cached = _host_gauss(float(xs[n2].item()), float(ar[n2 // 2].item()))
-            else:
-                cached = 0.0
-            pos += 4 * (last + 1)
-            out.append(torch.cat((torch.tensor(head, dtype=odt, device=dev), n32)) if head else n32)
+            out.append(torch.cat((torch.tensor(head, dtype=odt, device=dev), res)) if head else res)
         else:
-            has_gauss, cached = False, 0.0                               # the cached value was the whole draw
             out.append(torch.tensor(head, dtype=odt, device=dev))
-    d = Draw()
+        at += count
+    if n2 > 0 and (n2 & 1):                                  # exact: it is handed back to NumPy as generator state
+        has_gauss, cached = True, _host_gauss(float(xs[n2].item()), float(ar[n2 // 2].item()))
+    else:
+        has_gauss, cached = False, 0.0
     d.noise, d.position, d.has_gauss, d.gauss, d.patched = out, pos, has_gauss, cached, patched
     return d
 
@@ -173,7 +196,7 @@ def draw_on_device(requests: Sequence[tuple], device, f64: bool = False) -> List
     kind, key, pos, has_gauss, gauss = np.random.get_state()
     if kind != "MT19937":
         return None
-    total = sum(words_needed(n) for n, _ in requests if n)
+    total = words_needed(sum(n for n, _ in requests))
     nblocks = (int(pos) + total) // 624 + 2
     with torch.cuda.device(device):
         key_d = torch.from_numpy(key.astype(np.uint32).view(np.int32).copy()).to(device)

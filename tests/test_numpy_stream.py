@@ -43,7 +43,7 @@ def test_device_evaluation_equals_np_random_normal(seed, burn, requests):
     _, key, pos, has_gauss, gauss = st
     want = [np.random.normal(0, s, n).astype(np.float32) for n, s in requests]
     after = np.random.get_state()
-    total = sum(NS.words_needed(n) for n, _ in requests) + 700
+    total = NS.words_needed(sum(n for n, _ in requests)) + 700
     raw = raw_stream(key, total // 624 + 2)
     d = NS.normals(raw, pos, bool(has_gauss), float(gauss), requests)
     for got, w in zip(d.noise, want):
