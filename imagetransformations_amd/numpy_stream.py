@@ -184,7 +184,31 @@ def state_at(raw: torch.Tensor, position: int, start: int):
     return key, p
 
 
+PASS_NORMALS = 1 << 27       # normals per pass over the stream (the pass holds ~70 bytes per normal on the device for a moment)
+
+
 def draw_on_device(requests: Sequence[tuple], device, f64: bool = False) -> List[torch.Tensor] | None:
+    """_draw_pass over stretches of at most PASS_NORMALS normals (np.random's state carries from one to the next)."""
+    requests = [(int(n), float(s)) for n, s in requests]
+    out: List[torch.Tensor] = []
+    i = 0
+    while i < len(requests):
+        j, tot = i, 0
+        while j < len(requests) and (j == i or tot + requests[j][0] <= PASS_NORMALS):
+            tot += requests[j][0]
+            j += 1
+        got = _draw_pass(requests[i:j], device, f64)
+        if got is None:
+            if i == 0:
+                return None
+            got = [torch.from_numpy(np.random.normal(0, s, n) if f64 else np.random.normal(0, s, n).astype(np.float32)).to(device)
+                   for n, s in requests[i:j]]                    # (only if the generator changed kind in between)
+        out.extend(got)
+        i = j
+    return out
+
+
+def _draw_pass(requests: Sequence[tuple], device, f64: bool = False) -> List[torch.Tensor] | None:
     """The float32 results of `[np.random.normal(0, scale, count).astype(np.float32) for count, scale in requests]` as
     device tensors, with np.random's global state advanced exactly as those calls would have advanced it — or None (state
     untouched) if the global generator is not the legacy MT19937: the caller then makes the calls on the host."""

@@ -82,3 +82,18 @@ def test_pool_gaussian_noise_doubles_on_the_device(device, monkeypatch):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     s0, s1 = res[0][2], res[1][2]
     assert s0[2] == s1[2] and np.array_equal(s0[1], s1[1]) and s0[3] == s1[3] and (s0[4] == s1[4] or not s0[3])
+
+
+def test_passes_over_the_stream_hand_the_state_on(device, monkeypatch):
+    """Requests beyond PASS_NORMALS are served by several passes; np.random's state carries between them."""
+    monkeypatch.setattr(NS, "PASS_NORMALS", 5000)
+    requests = [(3001, 2.0), (1999, 1.0), (4000, 3.0), (7, 1.0), (9001, 0.5)]
+    np.random.seed(31)
+    want = [np.random.normal(0, s, n).astype(np.float32) for n, s in requests]
+    after = np.random.get_state()
+    np.random.seed(31)
+    got = NS.draw_on_device(requests, device)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.cpu().numpy(), w)
+    now = np.random.get_state()
+    assert now[2] == after[2] and np.array_equal(now[1], after[1]) and now[3] == after[3] and (now[4] == after[4] or not now[3])
