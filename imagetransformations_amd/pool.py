@@ -37,7 +37,12 @@ class TransformationPool:
         z = None
         if T.NOISE_RNG != "numpy-host" and img_array.size >= T.NOISE_DEVICE_MIN:    # the same doubles, computed on the device
             from . import numpy_stream
-            got = numpy_stream.draw_on_device([(img_array.size, noise_std * 255)], dev, f64=True)
+            state = np.random.get_state()
+            try:
+                got = numpy_stream.draw_on_device([(img_array.size, noise_std * 255)], dev, f64=True)
+            except ValueError:
+                np.random.set_state(state)
+                got = None
             z = got[0].view(img_array.shape) if got is not None else None
         if z is None:
             z = torch.from_numpy(np.random.normal(0, noise_std * 255, img_array.shape)).to(dev)

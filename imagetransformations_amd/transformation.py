@@ -200,7 +200,12 @@ def _numpy_noise(requests, dev):
     if NOISE_RNG == "numpy-host" or not requests or sum(n for n, _ in requests) < NOISE_DEVICE_MIN:
         return [None] * len(requests)               # (a CIFAR image is 3072 normals: 50 us on the host, less than one launch)
     from . import numpy_stream
-    got = numpy_stream.draw_on_device(requests, dev)
+    state = np.random.get_state()
+    try:
+        got = numpy_stream.draw_on_device(requests, dev)
+    except ValueError:                                  # fewer accepted groups than 12 standard deviations allow for: the host draws
+        np.random.set_state(state)
+        got = None
     return got if got is not None else [None] * len(requests)
 
 
