@@ -440,11 +440,33 @@ def apply_all_transformations_batched_named(images, _sink=None):
                     noise[(i, k)] = _noise_seed()
                 else:
                     draws.append((i, k, (h, w, 3), args[0] * 255))
+    pending_noise = None
     if draws:
         # nothing else touches np.random between these calls (the grid values come from `random`): one pass over the stream
-        # on the device serves them all, or the host makes them one by one
-        got = _numpy_noise([(h * w * c, scale) for _, _, (h, w, c), scale in draws], dev)
-        for (i, k, shape, scale), z in zip(draws, got):
+        # on the device serves them all, or the host makes them one by one.  The MT19937 block kernel (one workgroup) starts
+        # NOW on a side stream; the numbers are collected when the first noise group comes up, after the other transformation
+        # types have been queued (tensor_fns order puts 'gaussian_noise' wherever the reference's dict has it).
+        reqs = [(h * w * c, scale) for _, _, (h, w, c), scale in draws]
+        if NOISE_RNG != "numpy-host" and sum(n for n, _ in reqs) >= NOISE_DEVICE_MIN:
+            from . import numpy_stream
+            pending_noise = numpy_stream.PendingDraw(reqs, dev)
+        else:
+            for (i, k, shape, scale) in draws:
+                noise[(i, k)] = np.random.normal(0, scale, shape).astype(np.float32)
+
+    def collect_noise():
+        nonlocal pending_noise
+        if pending_noise is None:
+            return
+        p, pending_noise = pending_noise, None
+        state = p.state
+        try:
+            got = p.result()
+        except ValueError:                              # (a margin of 12 standard deviations was too short: the host draws)
+            np.random.set_state(state)
+            got = None
+        for n_, ((i, k, shape, scale)) in enumerate(draws):
+            z = got[n_] if got is not None else None
             noise[(i, k)] = z.view(shape) if z is not None else np.random.normal(0, scale, shape).astype(np.float32)
 
     results = [[None] * len(p) for p in plans]
@@ -478,7 +500,9 @@ def apply_all_transformations_batched_named(images, _sink=None):
         for row, i in enumerate(members):
             for k, (transform_type, args, _) in enumerate(plans[i]):
                 groups.setdefault((transform_type, args), []).append((row, i, k))
-        for (transform_type, args), entries in groups.items():
+        # (noise groups last: their numbers come from the side stream's generator, which runs meanwhile)
+        ordered = sorted(groups.items(), key=lambda g: g[0][0] == 'gaussian_noise')
+        for (transform_type, args), entries in ordered:
             rows = torch.tensor([e[0] for e in entries], device=dev)
             batch = frames.index_select(0, rows)
             if transform_type == 'blur':
@@ -493,6 +517,7 @@ def apply_all_transformations_batched_named(images, _sink=None):
                 for j, (_, i, k) in enumerate(entries):
                     out[j] = ops.add_noise_device(batch[j], args[0] * 255, noise[(i, k)])
             elif transform_type == 'gaussian_noise':
+                collect_noise()
                 zs = [noise[(i, k)] for _, i, k in entries]
                 z = torch.stack(zs) if isinstance(zs[0], torch.Tensor) else staging.upload(zs, dev)
                 out = ops.add_noise(batch, z)
