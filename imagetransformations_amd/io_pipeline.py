@@ -84,12 +84,16 @@ def _chunks(seq: Sequence, n: int) -> Iterable[Sequence]:
 
 def run_directory(data_path: str, out_dir: str, chunk_images: int = 256, workers: int = 8,
                   transform: Callable[[List[Tuple[Image.Image, str]]], List[Tuple[str, Image.Image]]] | None = None,
-                  encoder: str = "pillow", decoder: str = "pillow") -> int:
+                  encoder: str = "device", decoder: str | None = None) -> int:
     """load_data + apply_all_transformations + save over a directory, streamed.  `transform` maps a
     chunk [(image, path)] to [(file name, image)] in output order; default: the batched
-    eight-transformation driver.  Returns the number of files written.  `decoder="device"`: worker threads only READ the
+    eight-transformation driver.  Returns the number of files written.  Both on-disk steps default to the device since
+    round 3 (files byte-identical to Pillow's, pixels identical to Pillow's; "pillow" selects the host libraries the
+    reference uses; with a caller's own `transform` the decoder defaults to "pillow", since it receives PIL images).  `decoder="device"`: worker threads only READ the
     files; the chunk is decoded by the GPU reader (`jpeg_decode.decode`, pixels identical to Pillow's) and the frames
     go to the batched driver without ever visiting the host."""
+    if decoder is None:                                         # a caller's own `transform` is written against PIL images
+        decoder = "device" if transform is None else "pillow"
     device_driver = transform is None and encoder == "device"
     if transform is None:
         from .transformation import apply_all_transformations_batched_named as transform

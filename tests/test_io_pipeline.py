@@ -43,14 +43,14 @@ def test_streaming_order_and_chunking(tmp_path, capsys):
 
     for chunk_images in (1, 4, 5, 100):
         seen.clear()
-        n = IO.run_directory(src, dst, chunk_images=chunk_images, workers=3, transform=fake)
+        n = IO.run_directory(src, dst, chunk_images=chunk_images, workers=3, transform=fake, encoder="pillow")
         assert n == 11                                              # the broken file is reported and skipped
         flat = [b for c in seen for b in c]
         assert flat == [os.path.basename(p) for p in order if "broken" not in p]
         assert all(len(c) <= chunk_images for c in seen)
         assert sorted(os.listdir(dst)) == sorted(os.path.splitext(b)[0] + "_copy.jpg" for b in flat)
     assert "Failed to load image" in capsys.readouterr().out
-    assert IO.run_directory(str(tmp_path / "empty"), dst, transform=fake) == 0
+    assert IO.run_directory(str(tmp_path / "empty"), dst, transform=fake, encoder="pillow") == 0
 
 
 @pytest.mark.gpu
@@ -87,14 +87,14 @@ def test_device_decoder_gives_the_same_files(device, tmp_path):
     _make_tree(src)
     Image.fromarray(synth(77, 40, 56)).save(os.path.join(src, "n01", "prog.jpeg"), progressive=True, quality=80)
     outs = {}
-    for name, kw in (("pp", dict()), ("dp", dict(decoder="device")), ("dd", dict(decoder="device", encoder="device")),
-                     ("pd", dict(encoder="device"))):
+    for name, kw in (("pp", dict(decoder="pillow", encoder="pillow")), ("dp", dict(decoder="device", encoder="pillow")), ("dd", dict()),
+                     ("pd", dict(decoder="pillow", encoder="device"))):            # dd: the defaults
         dst = str(tmp_path / name)
         random.seed(9); np.random.seed(9)
         IO.DECODE_STATS.update(device=0, pillow=0)
         n = IO.run_directory(src, dst, chunk_images=5, workers=3, **kw)
         assert n == 8 * 12
-        if "decoder" in kw:
+        if kw.get("decoder", "device") == "device":
             assert IO.DECODE_STATS == {"device": 11, "pillow": 1}
         outs[name] = {f: open(os.path.join(dst, f), "rb").read() for f in sorted(os.listdir(dst))}
     assert outs["pp"].keys() == outs["dp"].keys() == outs["dd"].keys() == outs["pd"].keys()

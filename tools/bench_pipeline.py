@@ -21,11 +21,11 @@ for i in range(n):
     Image.fromarray(img).save(os.path.join(src, f"img_{i:05d}.JPEG"), quality=90)
 print(f"{n} files of {h}x{w} in {src}")
 try:
-    for name, kw, noise in (("Pillow decode, Pillow encode, NumPy noise (round 2 default)", dict(), "numpy"),
-                            ("Pillow decode, device encode, NumPy noise", dict(encoder="device"), "numpy"),
+    for name, kw, noise in (("Pillow decode, Pillow encode, NumPy noise (round 2 default)", dict(decoder="pillow", encoder="pillow"), "numpy"),
+                            ("Pillow decode, device encode, NumPy noise", dict(decoder="pillow", encoder="device"), "numpy"),
                             ("device decode, device encode, NumPy noise", dict(decoder="device", encoder="device"), "numpy"),
                             ("device decode, device encode, device noise", dict(decoder="device", encoder="device"), "device"),
-                            ("Pillow decode, Pillow encode, device noise", dict(), "device")):
+                            ("Pillow decode, Pillow encode, device noise", dict(decoder="pillow", encoder="pillow"), "device")):
         if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
             continue
         dst = tempfile.mkdtemp(prefix="imgxf_pipe_out_")
