@@ -321,8 +321,34 @@ def save_image(img: Image.Image, path: str) -> None:
         img.save(path)
 
 
+DRIVER = os.environ.get("IMGXF_DRIVER", "batched")       # "per-image": apply_all_transformations runs the reference's literal loop
+DRIVER_CHUNK = 256                                        # images per pass of the batched driver inside apply_all_transformations
+
+
 def apply_all_transformations(images):
-    """images: [(PIL image, path)] -> list of transformed PIL images (8 per input)."""
+    """images: [(PIL image, path)] -> list of transformed PIL images (8 per input), /root/reference/transformation.py:92-170.
+    Same draws (`random`, `np.random`), same names, same order, same pixels as the literal loop
+    (`apply_all_transformations_per_image`, which tests/test_gpu_facade.py holds it against); since late round 3 the work is
+    done DRIVER_CHUNK images at a time by the batched driver — images of one size share their uploads, launches and copies
+    back.  A chunk with an image that is not 8-bit RGB, and `IMGXF_DRIVER=per-image`, take the literal loop."""
+    if DRIVER == "per-image":
+        return apply_all_transformations_per_image(images)
+    images = list(images)
+    transformed_images = []
+    for c0 in range(0, len(images), DRIVER_CHUNK):
+        chunk = images[c0:c0 + DRIVER_CHUNK]
+        if all(_is_rgb(img) for img, _ in chunk):
+            transformed_images.extend(apply_all_transformations_batched(chunk))
+        else:
+            transformed_images.extend(apply_all_transformations_per_image(chunk, _progress=False))
+        done = c0 + len(chunk)
+        for mark in range((c0 // 1000 + 1) * 1000, done + 1, 1000):     # the reference's progress line, per thousand images
+            print(f"Processed {mark}/{len(images)} original images, created {8 * mark} transformed images")
+    return transformed_images
+
+
+def apply_all_transformations_per_image(images, _progress: bool = True):
+    """The reference's loop, call by call: one upload, one launch and one copy back per transformation."""
     transformed_images = []
     total_transforms = 0
     for i, (img, path) in enumerate(images):
@@ -334,7 +360,7 @@ def apply_all_transformations(images):
                 save_image(transformed_img, os.path.join(output_dir, new_filename))
             transformed_images.append(transformed_img)
             total_transforms += 1
-        if (i + 1) % 1000 == 0:
+        if _progress and (i + 1) % 1000 == 0:
             print(f"Processed {i + 1}/{len(images)} original images, created {total_transforms} transformed images")
     return transformed_images
 

@@ -415,7 +415,7 @@ def test_batched_driver_equals_per_image_driver(device):
             for i, hw in enumerate([(32, 32), (48, 64), (32, 32), (37, 61), (48, 64), (32, 32), (32, 32)])]
     for seed in (0, 1, 2):
         random.seed(seed); np.random.seed(seed)
-        want = T.apply_all_transformations(imgs)
+        want = T.apply_all_transformations_per_image(imgs)
         random.seed(seed); np.random.seed(seed)
         got = T.apply_all_transformations_batched(imgs)
         assert len(got) == len(want) == 8 * len(imgs)
@@ -454,3 +454,24 @@ def test_histogram_equalization_matches_oracle(device):
     for i in range(2):
         want = batch[i].copy(); want[..., 0] = O.equalize_hist_cv(batch[i][..., 0])
         assert np.array_equal(out[i], want)
+
+
+def test_apply_all_transformations_in_chunks_equals_the_literal_loop(device, monkeypatch, capsys):
+    """The drop-in's main entry now runs the batched driver DRIVER_CHUNK images at a time: same draws, names, order and pixels
+    as the reference's literal loop, across chunk boundaries, with a chunk that holds a non-RGB image, and with
+    IMGXF_DRIVER=per-image."""
+    from imagetransformations_amd import transformation as T
+    imgs = [(Image.fromarray(synth(150 + i, *hw)), f"/data/img_{i}.JPEG")
+            for i, hw in enumerate([(32, 32), (48, 64), (32, 32), (37, 61), (48, 64), (32, 32), (32, 32), (40, 40)])]
+    monkeypatch.setattr(T, "DRIVER_CHUNK", 3)
+    random.seed(4); np.random.seed(4)
+    want = T.apply_all_transformations_per_image(imgs)
+    random.seed(4); np.random.seed(4)
+    got = T.apply_all_transformations(imgs)
+    assert len(got) == len(want) == 64
+    for a, b in zip(got, want):
+        assert a.size == b.size and a.mode == b.mode and np.array_equal(np.asarray(a), np.asarray(b))
+    monkeypatch.setattr(T, "DRIVER", "per-image")
+    random.seed(4); np.random.seed(4)
+    again = T.apply_all_transformations(imgs)
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(again, want))

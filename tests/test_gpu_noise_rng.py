@@ -82,7 +82,7 @@ def test_facade_opt_in_keeps_seeded_runs_repeatable(device, monkeypatch):
     import random
     imgs = [(Image.fromarray(synth(970 + i, 48, 64)), f"/x/im{i}.JPEG") for i in range(3)]
     monkeypatch.setattr(T, "output_dir", None)
-    random.seed(11); np.random.seed(11); one = T.apply_all_transformations(imgs)
+    random.seed(11); np.random.seed(11); one = T.apply_all_transformations_per_image(imgs)
     random.seed(11); np.random.seed(11); many = T.apply_all_transformations_batched(imgs)
     assert len(one) == len(many) == 24
     for p, q in zip(one, many):

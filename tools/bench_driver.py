@@ -12,8 +12,8 @@ h = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 w = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 rng = np.random.default_rng(0)
 imgs = [(Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)), f"img_{i}.jpeg") for i in range(n)]
-T.apply_all_transformations_batched(imgs[:8]); T.apply_all_transformations(imgs[:8])   # warm up
-for name, fn in (("per-image", T.apply_all_transformations), ("batched", T.apply_all_transformations_batched)):
+T.apply_all_transformations_batched(imgs[:8]); T.apply_all_transformations_per_image(imgs[:8])   # warm up
+for name, fn in (("per-image", T.apply_all_transformations_per_image), ("batched", T.apply_all_transformations_batched)):
     random.seed(0); np.random.seed(0)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = fn(imgs)
