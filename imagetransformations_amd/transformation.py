@@ -366,7 +366,11 @@ def apply_all_transformations_per_image(images, _progress: bool = True):
 
 
 def apply_all_transformations_batched(images):
-    """`apply_all_transformations_batched_named` + the reference's save step (:159-162)."""
+    """`apply_all_transformations_batched_named` + the reference's save step (:159-162).  With `output_dir` set the files are
+    written by the device writer (byte-identical to Pillow's `save`, tests/test_gpu_jpeg.py) while the images still come back;
+    `IMGXF_SAVE=pillow` keeps Pillow's encoder."""
+    if output_dir is not None and os.environ.get("IMGXF_SAVE", "device") == "device":
+        return [img for _, img in _batched_to_files(images, output_dir, tee=True)]
     transformed_images = []
     for new_filename, img in apply_all_transformations_batched_named(images):
         if output_dir is not None:
@@ -376,15 +380,23 @@ def apply_all_transformations_batched(images):
 
 
 def apply_all_transformations_batched_to_files(images, out_dir: str) -> List[str]:
+    """The batched driver with the save step on the device and NO images copied back: returns the file names in output order
+    (`_batched_to_files`)."""
+    return [name for name, _ in _batched_to_files(images, out_dir, tee=False)]
+
+
+def _batched_to_files(images, out_dir: str, tee: bool):
     """The batched driver with the save step (:159-162) on the device too: every group's result goes from the transform
     kernels straight into the JPEG writer (`jpeg.encode`), and only the files — a tenth of a byte per pixel for
     photographs instead of three — cross PCIe.  Same draws, names, order and FILES as `apply_all_transformations_batched`
-    with `output_dir` set (Pillow's encoder): tests/test_gpu_jpeg.py.  Returns the file names in output order."""
+    with `output_dir` set (Pillow's encoder): tests/test_gpu_jpeg.py.  Returns [(file name, image or None)] in output order:
+    `tee` also copies the results back as PIL images (apply_all_transformations_batched with `output_dir` set)."""
     from . import jpeg
     os.makedirs(out_dir, exist_ok=True)
     # Groups are small (a handful of frames per transformation type and parameter) and a writer call costs ~0.4 ms of host
     # time whatever its size: results are collected per frame shape and encoded SINK_FRAMES at a time.
     held: dict = {}                                       # frame shape -> ([tensors], [names], frames)
+    written: set = set()                                  # names the sink has put on disk
 
     def flush(shape) -> None:
         # (the files are written here, by this thread: a side thread pays a GIL hand-over per system call while this one
@@ -394,6 +406,7 @@ def apply_all_transformations_batched_to_files(images, out_dir: str) -> List[str
         for name, data in zip(names, jpeg.encode_views(big)):
             with open(os.path.join(out_dir, name), "wb") as f:
                 f.write(data)
+        written.update(names)
 
     def sink(out: torch.Tensor, names: List[str]) -> None:
         on_device = [n.lower().endswith((".jpg", ".jpeg")) for n in names]
@@ -407,16 +420,20 @@ def apply_all_transformations_batched_to_files(images, out_dir: str) -> List[str
             host = staging.download(out).numpy()
             for j, name in enumerate(names):
                 Image.fromarray(host[j]).save(os.path.join(out_dir, name))
+            written.update(names)
 
-    named = apply_all_transformations_batched_named(images, _sink=sink)
+    named = apply_all_transformations_batched_named(images, _sink=sink, _tee=tee)
+    sunk = set()
+    if tee:                                               # the names the sink has written: everything else is saved below
+        sunk = {n for _, names, _ in held.values() for n in names} | written
     for name, img in named:
         if isinstance(img, torch.Tensor):                 # apply_blur's radius-0 pass-through of a device frame
             sink(img[None], [name])
-        elif img is not None:                             # per-image path (not RGB) or apply_blur's radius-0 pass-through
+        elif img is not None and name not in sunk:        # per-image path (not RGB) or apply_blur's radius-0 pass-through
             save_image(img, os.path.join(out_dir, name))
     for shape in list(held):
         flush(shape)
-    return [name for name, _ in named]
+    return named
 
 
 SINK_FRAMES = 1024                                        # frames of one shape per writer call in the device-save drivers ...
@@ -442,7 +459,7 @@ def _collect(item, results) -> int:
     return host.nbytes
 
 
-def apply_all_transformations_batched_named(images, _sink=None):
+def apply_all_transformations_batched_named(images, _sink=None, _tee=False):
     """`apply_all_transformations` with the work grouped for the GPU, returning
     [(file name, image)] in the reference's output order and saving nothing: same draws (`random` per
     transform type per image, `np.random` for the noise, in the reference's order), same file
@@ -551,7 +568,8 @@ def apply_all_transformations_batched_named(images, _sink=None):
                 out = tensor_fns[transform_type](batch, *args)
             if _sink is not None:
                 _sink(out, [plans[i][k][2] for _, i, k in entries])
-                continue
+                if not _tee:
+                    continue
             # queue the copy back and keep launching: the host waits per result only when it builds the images.
             # The window of copies in flight is bounded (staging.PENDING_BUDGET bytes of pinned memory): beyond
             # it the oldest results are turned into images before the next group is queued

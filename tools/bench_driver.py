@@ -29,7 +29,7 @@ if os.environ.get("SAVE", "1") == "1":
         base = 128 + 60 * np.sin(xx / 37.0) + 50 * np.cos(yy / 29.0)
         imgs = [(Image.fromarray(np.clip(base[..., None] + 10 * (i % 7) + rng.normal(0, 5, (h, w, 3)), 0, 255).astype(np.uint8)),
                  f"img_{i}.jpeg") for i in range(n)]
-    for name in ("batched + Pillow save", "batched, save on device"):
+    for name in ("batched, output_dir set", "batched, save on device"):
         d = tempfile.mkdtemp(prefix="imgxf_bench_")
         try:
             random.seed(0); np.random.seed(0)
