@@ -127,6 +127,80 @@ __global__ __launch_bounds__(256) void mt19937_blocks_kernel(const u32* __restri
 }
 } // namespace imgxf
 
+namespace imgxf {
+// Jump-ahead (Haramoto et al.): out_keys[w] = F^((w+1) J) base = g_(w+1)(F) base, where F is the generator's one-word step on its
+// canonical state (S[t] .. S[t+623]) and g_m = x^(m J) mod (F's characteristic polynomial), evaluated by Horner's rule:
+// r = 0; for i = deg .. 0: r = F r (+ s if g_i).  One wave per jump (no barriers: a wave's LDS operations execute in order): lane 0
+// makes the step on a circular buffer — one new word per step — and the 64 lanes add s where the coefficient is set (half of
+// the 19937 steps): 9 ms per jump, all jumps of a request in parallel.  coefs: [jump][2496] bytes, bit i of the little-endian bit
+// string = coefficient i (tools/make_mt_jump.py).
+__global__ __launch_bounds__(64) void mt19937_jump_kernel(const u32* __restrict__ base, u32* __restrict__ out_keys, const u8* __restrict__ coefs) {
+    __shared__ u32 s[624], r[624];
+    __shared__ u8 g[2496];
+    const int lane = threadIdx.x;
+    const u8* coef = coefs + (size_t)blockIdx.x * 2496;              // workgroup w: out_keys[w] = g_(w+1)(F) base = F^((w+1) J) base
+    for (int i = lane; i < 2496; i += 64) g[i] = coef[i];
+    for (int i = lane; i < 624; i += 64) { s[i] = base[i]; r[i] = 0u; }
+    __syncthreads();
+    int h = 0;                                                       // logical word j of r lives at r[(h + j) % 624]
+    for (int i = 19936; i >= 0; --i) {
+        if (lane == 0) {
+            const u32 a = r[h], b = r[h + 1 < 624 ? h + 1 : 0], c = r[h + 397 < 624 ? h + 397 : h + 397 - 624];
+            const u32 y = (a & 0x80000000u) | (b & 0x7fffffffu);
+            r[h] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        h = h + 1 < 624 ? h + 1 : 0;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((g[i >> 3] >> (i & 7)) & 1) {
+            for (int j = lane; j < 624; j += 64) { const int p = h + j < 624 ? h + j : h + j - 624; r[p] ^= s[j]; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    for (int j = lane; j < 624; j += 64) out_keys[(size_t)blockIdx.x * 624 + j] = r[h + j < 624 ? h + j : h + j - 624];
+}
+
+// The state sequence in STRETCHES of `bps` blocks: workgroup m starts from keys[m] (= block m * bps of the stream) and writes
+// blocks m * bps .. min((m + 1) * bps, total) - 1 (the loop of mt19937_blocks_kernel).
+__global__ __launch_bounds__(256) void mt19937_stretch_kernel(const u32* __restrict__ keys, u32* __restrict__ out, long long bps, long long total) {
+    __shared__ u32 st[2][624];
+    const int tid = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * bps, b1 = b0 + bps < total ? b0 + bps : total;
+    if (b0 >= total) return;
+    const u32* key = keys + (size_t)blockIdx.x * 624;
+    // (a jumped key's word 0 is state only in its top bit: the stream's word there is written by the stretch before, below)
+    for (int i = tid; i < 624; i += 256) { const u32 v = key[i]; st[0][i] = v; if (i || blockIdx.x == 0) out[b0 * 624 + i] = v; }
+    __syncthreads();
+    auto twist = [](u32 u, u32 v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); };
+    for (long long b = b0 + 1; b < b1; ++b) {
+        const u32* o = st[(b - b0 - 1) & 1];
+        u32* n = st[(b - b0) & 1];
+        u32* dst = out + b * 624;
+        if (tid < 227) {
+            const u32 a = o[tid + 397] ^ twist(o[tid], o[tid + 1]);
+            const u32 c = a ^ twist(o[227 + tid], o[228 + tid]);
+            n[tid] = a; n[227 + tid] = c;
+            dst[tid] = a; dst[227 + tid] = c;
+            if (tid < 169) {
+                const u32 e = c ^ twist(o[454 + tid], o[455 + tid]);
+                n[454 + tid] = e; dst[454 + tid] = e;
+            }
+            if (tid == 0) {
+                const u32 n169 = o[566] ^ twist(o[169], o[170]);
+                const u32 n396 = n169 ^ twist(o[396], o[397]);
+                const u32 z = n396 ^ twist(o[623], a);
+                n[623] = z; dst[623] = z;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (b1 < total && tid == 0) {                                      // word 0 of the next stretch's first block
+        const u32* o = st[(b1 - b0 - 1) & 1];
+        out[b1 * 624] = o[397] ^ twist(o[0], o[1]);
+    }
+}
+} // namespace imgxf
+
 using namespace imgxf;
 
 IMGXF_API int imgxf_add_noise_philox_u8(const imgxf_view* src, const imgxf_view* dst, float sigma, uint64_t seed,
@@ -156,5 +230,21 @@ IMGXF_API int imgxf_mt19937_blocks(const uint32_t* key, uint32_t* out, int64_t n
     if (!key || !out) return IMGXF_ERR_NULL;
     if (nblocks < 0) return IMGXF_ERR_ARG;
     hipLaunchKernelGGL(mt19937_blocks_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, key, out, (long long)nblocks);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_mt19937_jump(const uint32_t* base_key, uint32_t* out_keys, int n_out, const uint8_t* coefs, void* stream) {
+    if (!base_key || !out_keys || !coefs) return IMGXF_ERR_NULL;
+    if (n_out < 0) return IMGXF_ERR_ARG;
+    if (n_out > 0) hipLaunchKernelGGL(mt19937_jump_kernel, dim3((unsigned)n_out), dim3(64), 0, (hipStream_t)stream, base_key, out_keys, coefs);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_mt19937_stretches(const uint32_t* keys, uint32_t* out, int n_stretches, int64_t blocks_per_stretch, int64_t total_blocks,
+                                      void* stream) {
+    if (!keys || !out) return IMGXF_ERR_NULL;
+    if (n_stretches < 1 || blocks_per_stretch < 1 || total_blocks < 1) return IMGXF_ERR_ARG;
+    hipLaunchKernelGGL(mt19937_stretch_kernel, dim3((unsigned)n_stretches), dim3(256), 0, (hipStream_t)stream, keys, out,
+                       (long long)blocks_per_stretch, (long long)total_blocks);
     return launch_status();
 }

@@ -23,6 +23,7 @@ and patched in, as is the cached second normal that an odd-length draw hands bac
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Sequence
 
 import numpy as np
@@ -184,6 +185,68 @@ def state_at(raw: torch.Tensor, position: int, start: int):
     return key, p
 
 
+
+# ---- the state sequence, sequentially or in stretches ---------------------------------------------------------------
+_JUMP = {"state": None}          # None: not tried yet; False: unavailable / failed its self-check; dict: coefficients on the device
+
+
+def _jump_tables(device: torch.device):
+    """The jump polynomial for a stride of 624 * 2^k words (imagetransformations_amd/mt19937_jump.npz, written and checked on
+    the host by tools/make_mt_jump.py) on the device — after a one-time check of the device kernels against the sequential
+    generator (one stride: 19 ms)."""
+    from . import _ffi as F
+    st = _JUMP["state"]
+    if st is not None:
+        return st if st else None
+    _JUMP["state"] = False
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mt19937_jump.npz")
+    if not os.path.exists(path) or os.environ.get("IMGXF_MT_JUMP", "1") == "0":
+        return None
+    z = np.load(path)
+    bps = 1 << int(z["log2_blocks"])
+    coef = torch.from_numpy(z["coef"].astype(np.uint8).copy()).to(device)
+    with torch.cuda.device(device):
+        cs = torch.cuda.current_stream(device).cuda_stream
+        key = np.random.RandomState(20240229).get_state()[1].astype(np.uint32)
+        keys = torch.zeros((3, 624), dtype=torch.int32, device=device)
+        keys[0] = torch.from_numpy(key.view(np.int32).copy()).to(device)
+        F.call("imgxf_mt19937_jump", keys.data_ptr(), keys[1:].data_ptr(), 2, coef.data_ptr(), cs)
+        seq = torch.empty(((2 * bps + 1) * 624,), dtype=torch.int32, device=device)
+        F.call("imgxf_mt19937_blocks", keys.data_ptr(), seq.data_ptr(), 2 * bps, cs)
+        ok = True
+        for m in (1, 2):                                             # (only the top bit of word 0 is state)
+            a, b = keys[m].to(torch.int64) & 0xFFFFFFFF, seq[m * bps * 624:(m * bps + 1) * 624].to(torch.int64) & 0xFFFFFFFF
+            ok = ok and bool((a[1:] == b[1:]).all()) and int(a[0]) >> 31 == int(b[0]) >> 31
+    if ok:
+        _JUMP["state"] = {"coef": coef, "bps": bps, "jumps": int(coef.shape[0])}
+        return _JUMP["state"]
+    return None
+
+
+def generate_stream(key_d: torch.Tensor, nblocks: int, device: torch.device, cuda_stream: int) -> torch.Tensor:
+    """(nblocks + 1) * 624 raw state words from the key (int32 device tensor of 624 words): block 0 = the key.  Long requests
+    are cut into stretches of 2^k blocks whose start states come from the jump-ahead kernel (sequential, ~3 ms each) and which
+    are then generated by one workgroup each — the block recurrence itself is serial (290 ns per block)."""
+    from . import _ffi as F
+    total = nblocks + 1
+    raw = torch.empty((total * 624,), dtype=torch.int32, device=device)
+    jt = _jump_tables(device) if total > (1 << 15) else None
+    if jt is None or total <= jt["bps"]:
+        F.call("imgxf_mt19937_blocks", key_d.data_ptr(), raw.data_ptr(), nblocks, cuda_stream)
+        return raw
+    n_st = -(-total // jt["bps"])
+    keys = torch.empty((n_st, 624), dtype=torch.int32, device=device)
+    keys[0] = key_d
+    done = 1                                                 # every jump of a launch starts from the same key and runs in parallel
+    while done < n_st:
+        k = min(jt["jumps"], n_st - done)
+        F.call("imgxf_mt19937_jump", keys[done - 1].data_ptr(), keys[done].data_ptr(), k, jt["coef"].data_ptr(), cuda_stream)
+        done += k
+    F.call("imgxf_mt19937_stretches", keys.data_ptr(), raw.data_ptr(), n_st, jt["bps"], total, cuda_stream)
+    # (word 0 of a jumped key is state only in its top bit: the stream's word at a stretch boundary is written by the stretch
+    # before it, one step past its last block)
+    return raw
+
 PASS_NORMALS = 1 << 27       # normals per pass over the stream (the pass holds ~70 bytes per normal on the device for a moment)
 
 
@@ -224,8 +287,7 @@ def _draw_pass(requests: Sequence[tuple], device, f64: bool = False) -> List[tor
     nblocks = (int(pos) + total) // 624 + 2
     with torch.cuda.device(device):
         key_d = torch.from_numpy(key.astype(np.uint32).view(np.int32).copy()).to(device)
-        raw = torch.empty(((nblocks + 1) * 624,), dtype=torch.int32, device=device)
-        F.call("imgxf_mt19937_blocks", key_d.data_ptr(), raw.data_ptr(), nblocks, torch.cuda.current_stream(device).cuda_stream)
+        raw = generate_stream(key_d, nblocks, device, torch.cuda.current_stream(device).cuda_stream)
         d = normals(raw, int(pos), bool(has_gauss), float(gauss), requests, f64)
         if d.position != int(pos) or bool(has_gauss) != d.has_gauss:
             k, p = state_at(raw, d.position, int(pos))
@@ -257,8 +319,7 @@ class PendingDraw:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 self.key_d = torch.from_numpy(key.astype(np.uint32).view(np.int32).copy()).to(self.device)
-                self.raw = torch.empty(((nblocks + 1) * 624,), dtype=torch.int32, device=self.device)
-                F.call("imgxf_mt19937_blocks", self.key_d.data_ptr(), self.raw.data_ptr(), nblocks, self.side.cuda_stream)
+                self.raw = generate_stream(self.key_d, nblocks, self.device, self.side.cuda_stream)
             self.done = torch.cuda.Event()
             self.done.record(self.side)
 

@@ -410,6 +410,16 @@ int imgxf_jpeg_unstuff_host(const uint8_t* data, size_t n, size_t start, uint8_t
  * sequential in the block index.  Tempering, legacy_double and the polar method follow in imagetransformations_amd/numpy_stream.py. */
 int imgxf_mt19937_blocks(const uint32_t* key, uint32_t* out, int64_t nblocks, void* stream);
 
+/* The same sequence in parallel.  imgxf_mt19937_jump: out_keys[w * 624 ..] = the generator's canonical state (w + 1) * J words
+ * after base_key[0 .. 623], for w = 0 .. n_out - 1, all in parallel; J = 624 * 2^k words is the stride whose jump polynomials
+ * `coefs` holds ([n_out][2496] bytes: 19937 coefficients each, little-endian bits; imagetransformations_amd/mt19937_jump.npz,
+ * written and checked by tools/make_mt_jump.py).  Word 0 of a jumped state is state only in its top bit.
+ * imgxf_mt19937_stretches: workgroup m writes blocks m * blocks_per_stretch .. of the state sequence from keys[m]; total_blocks
+ * in all.  Together they produce exactly what imgxf_mt19937_blocks produces. */
+int imgxf_mt19937_jump(const uint32_t* base_key, uint32_t* out_keys, int n_out, const uint8_t* coefs, void* stream);
+int imgxf_mt19937_stretches(const uint32_t* keys, uint32_t* out, int n_stretches, int64_t blocks_per_stretch, int64_t total_blocks,
+                            void* stream);
+
 /* Why a file is outside the reader's class, or damaged (status[] of imgxf_jpeg_layout_host; 0 = accepted). */
 enum { IMGXF_JPEG_E_NOT_JPEG = 1,    /* no SOI */
        IMGXF_JPEG_E_MARKERS = 2,     /* damaged marker structure (also: SOS before SOF) */

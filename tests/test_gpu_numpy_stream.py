@@ -97,3 +97,39 @@ def test_passes_over_the_stream_hand_the_state_on(device, monkeypatch):
         assert np.array_equal(g.cpu().numpy(), w)
     now = np.random.get_state()
     assert now[2] == after[2] and np.array_equal(now[1], after[1]) and now[3] == after[3] and (now[4] == after[4] or not now[3])
+
+
+def test_jump_ahead_stretches_equal_the_sequential_stream(device):
+    """The state sequence generated in stretches (imgxf_mt19937_jump + imgxf_mt19937_stretches, stride = 624 * 2^16 words from
+    mt19937_jump.npz) is word for word the sequential one — across three stretch boundaries, for a key in the middle of its life."""
+    tables = NS._jump_tables(torch.device(device))
+    assert tables is not None, "the jump polynomial failed its self-check"
+    bps = tables["bps"]
+    rs = np.random.RandomState(4242)
+    rs.random_sample(100000)                              # a state some blocks into its stream
+    key = rs.get_state()[1].astype(np.uint32)
+    key_d = torch.from_numpy(key.view(np.int32).copy()).to(device)
+    nblocks = 3 * bps + 1234
+    st = torch.cuda.current_stream().cuda_stream
+    par = NS.generate_stream(key_d, nblocks, torch.device(device), st)
+    seq = torch.empty(((nblocks + 1) * 624,), dtype=torch.int32, device=device)
+    F.call("imgxf_mt19937_blocks", key_d.data_ptr(), seq.data_ptr(), nblocks, st)
+    assert torch.equal(par, seq)
+
+
+def test_a_draw_longer_than_a_stretch_is_np_random_normal(device):
+    """64 ImageNet-size images' worth of normals in one call: the stream comes from several stretches."""
+    n = 375 * 500 * 3
+    requests = [(n, 0.05 * 255 + i) for i in range(64)]
+    np.random.seed(123)
+    st = np.random.get_state()
+    want_first = np.random.normal(0, requests[0][1], n).astype(np.float32)
+    for _, s in requests[1:-1]:
+        np.random.normal(0, s, n)
+    want_last = np.random.normal(0, requests[-1][1], n).astype(np.float32)
+    after = np.random.get_state()
+    np.random.set_state(st)
+    got = NS.draw_on_device(requests, device)
+    assert np.array_equal(got[0].cpu().numpy(), want_first) and np.array_equal(got[-1].cpu().numpy(), want_last)
+    now = np.random.get_state()
+    assert now[2] == after[2] and np.array_equal(now[1], after[1]) and now[3] == after[3] and (now[4] == after[4] or not now[3])
