@@ -100,6 +100,9 @@ SIGNATURES = {
     "imgxf_jpeg_workspace_bytes": [C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_size_t)],
     "imgxf_jpeg_encode_u8": [_VP, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                              C.c_void_p],
+    "imgxf_np_accept": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
+    "imgxf_np_normals_f32": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     "imgxf_mt19937_jump": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "imgxf_mt19937_stretches": [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p],
     "imgxf_mt19937_blocks": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],

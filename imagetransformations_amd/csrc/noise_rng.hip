@@ -201,6 +201,67 @@ __global__ __launch_bounds__(256) void mt19937_stretch_kernel(const u32* __restr
 }
 } // namespace imgxf
 
+namespace imgxf {
+// NumPy's legacy_gauss over the word stream, data parallel (imagetransformations_amd/numpy_stream.py states the algorithm):
+// group g = words 4 g .. 4 g + 3 of the tempered stream -> (x1, x2, r2); accepted iff 0 < r2 < 1.
+__device__ __forceinline__ u32 mt_temper(u32 y) {
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+__device__ __forceinline__ void np_group(const u32* __restrict__ w, double& x1, double& x2, double& r2) {
+    const u32 a = mt_temper(w[0]) >> 5, b = mt_temper(w[1]) >> 6, c = mt_temper(w[2]) >> 5, d = mt_temper(w[3]) >> 6;
+    const double u1 = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;          // legacy_double
+    const double u2 = ((double)c * 67108864.0 + (double)d) / 9007199254740992.0;
+    x1 = 2.0 * u1 - 1.0; x2 = 2.0 * u2 - 1.0;
+    r2 = x1 * x1 + x2 * x2;
+}
+
+__global__ __launch_bounds__(256) void np_accept_kernel(const u32* __restrict__ words, long long ngroups, u8* __restrict__ acc) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ngroups) return;
+    double x1, x2, r2;
+    np_group(words + 4 * g, x1, x2, r2);
+    acc[g] = (r2 < 1.0 && r2 != 0.0) ? 1 : 0;
+}
+
+// rank[g] = inclusive prefix sum of acc.  Accepted group with rank k <= groups yields normals 2 (k - 1) (= f x2) and 2 (k - 1) + 1
+// (= f x1) of the stream; normal e belongs to the request whose [begin, end) holds e + lead (lead = 1 if a cached normal comes
+// first) and is scaled by its scale: out[e + lead] = float(0.0 + scale * f x).  A sample within `margin` (relative) of a float32
+// rounding boundary is appended to risky[] (its index e, for the host's libm); info[0] = index of the groups-th accepted group,
+// info[1] = number of risky samples, xr[0 .. 1] = (x1, r2) of that last group (the normal an odd count leaves cached).
+struct NpReq { long long begin; double scale; };
+__global__ __launch_bounds__(256) void np_normals_kernel(const u32* __restrict__ words, long long ngroups, const long long* __restrict__ rank,
+                                                         long long groups, long long n2, int lead, const NpReq* __restrict__ reqs, int nreq,
+                                                         double margin, float* __restrict__ out, long long* __restrict__ info,
+                                                         long long* __restrict__ risky, long long risky_cap, double* __restrict__ xr) {
+    // (xr[0 .. 1]: the last group's (x1, r2); xr[2 + 2 slot ..]: (x, r2) of risky sample `slot`)
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ngroups) return;
+    const long long k = rank[g];
+    const long long prev = g ? rank[g - 1] : 0;
+    if (k == prev || k > groups) return;                             // rejected, or beyond what the draw consumes
+    double x1, x2, r2;
+    np_group(words + 4 * g, x1, x2, r2);
+    const double f = sqrt(-2.0 * log(r2) / r2);
+    if (k == groups) { info[0] = g; xr[0] = x1; xr[1] = r2; }
+    const double xs[2] = {x2, x1};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const long long e = 2 * (k - 1) + h;
+        if (e >= n2) break;
+        const long long pos = e + lead;
+        int lo = 0, hi = nreq - 1;                                   // the request whose range holds pos
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (reqs[mid].begin <= pos) lo = mid; else hi = mid - 1; }
+        const double nd = 0.0 + reqs[lo].scale * (f * xs[h]);
+        out[pos] = (float)nd;
+        if ((float)(nd * (1.0 - margin)) != (float)(nd * (1.0 + margin))) {
+            const long long slot = (long long)atomicAdd((unsigned long long*)&info[1], 1ull);
+            if (slot < risky_cap) { risky[slot] = e; xr[2 + 2 * slot] = xs[h]; xr[3 + 2 * slot] = r2; }
+        }
+    }
+}
+} // namespace imgxf
+
 using namespace imgxf;
 
 IMGXF_API int imgxf_add_noise_philox_u8(const imgxf_view* src, const imgxf_view* dst, float sigma, uint64_t seed,
@@ -246,5 +307,23 @@ IMGXF_API int imgxf_mt19937_stretches(const uint32_t* keys, uint32_t* out, int n
     if (n_stretches < 1 || blocks_per_stretch < 1 || total_blocks < 1) return IMGXF_ERR_ARG;
     hipLaunchKernelGGL(mt19937_stretch_kernel, dim3((unsigned)n_stretches), dim3(256), 0, (hipStream_t)stream, keys, out,
                        (long long)blocks_per_stretch, (long long)total_blocks);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_np_accept(const uint32_t* words, int64_t ngroups, uint8_t* acc, void* stream) {
+    if (!words || !acc) return IMGXF_ERR_NULL;
+    if (ngroups < 0 || ngroups > ((int64_t)1 << 39)) return IMGXF_ERR_ARG;
+    if (ngroups) hipLaunchKernelGGL(np_accept_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, words, (long long)ngroups, acc);
+    return launch_status();
+}
+
+IMGXF_API int imgxf_np_normals_f32(const uint32_t* words, int64_t ngroups, const int64_t* rank, int64_t groups, int64_t n2, int lead,
+                                   const void* reqs, int nreq, double margin, float* out, int64_t* info, int64_t* risky,
+                                   int64_t risky_cap, double* xr, void* stream) {
+    if (!words || !rank || !reqs || !out || !info || !risky || !xr) return IMGXF_ERR_NULL;
+    if (ngroups < 0 || ngroups > ((int64_t)1 << 39) || nreq < 1 || lead < 0 || lead > 1) return IMGXF_ERR_ARG;
+    if (ngroups) hipLaunchKernelGGL(np_normals_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, words, (long long)ngroups,
+                                    (const long long*)rank, (long long)groups, (long long)n2, lead, (const NpReq*)reqs, nreq, margin, out,
+                                    (long long*)info, (long long*)risky, (long long)risky_cap, xr);
     return launch_status();
 }

@@ -106,6 +106,8 @@ def normals(raw: torch.Tensor, start: int, has_gauss: bool, gauss: float, reques
         d.position, d.has_gauss, d.gauss, d.patched = pos, has_gauss, float(gauss), 0
         return d
     n2 = total - (1 if has_gauss else 0)                     # normals to take from new groups
+    if raw.is_cuda and not f64 and raw.dtype == torch.int32 and os.environ.get("IMGXF_NP_FUSED", "1") != "0":
+        return _normals_fused(raw, pos, has_gauss, float(gauss), requests, counts, total, n2)
     xs = ar = None
     if n2 > 0:
         groups = (n2 + 1) // 2
@@ -171,6 +173,71 @@ def normals(raw: torch.Tensor, start: int, has_gauss: bool, gauss: float, reques
     else:
         has_gauss, cached = False, 0.0
     d.noise, d.position, d.has_gauss, d.gauss, d.patched = out, pos, has_gauss, cached, patched
+    return d
+
+
+RISKY_CAP = 1 << 16
+
+
+def _normals_fused(raw, pos, has_gauss, gauss, requests, counts, total, n2) -> Draw:
+    """`normals` for float32 results on the device in two kernels around one prefix sum (imgxf_np_accept, torch.cumsum,
+    imgxf_np_normals_f32) instead of a few dozen elementwise passes; the same arithmetic, statement by statement."""
+    from . import _ffi as F
+    dev = raw.device
+    d = Draw()
+    lead = 1 if has_gauss else 0
+    out = torch.empty((total,), dtype=torch.float32, device=dev)
+    begins, at = [], 0
+    for c in counts:
+        begins.append(at)
+        at += c
+    live = [(b, float(s)) for b, c, (_, s) in zip(begins, counts, requests) if c]
+    if has_gauss:
+        out[0] = float(np.float32(0.0 + live[0][1] * gauss))
+    patched = 0
+    if n2 > 0:
+        groups = (n2 + 1) // 2
+        w = words_needed(n2)
+        if pos + w > raw.numel():
+            raise ValueError("the MT19937 stream is shorter than the draw's margin")
+        ng = w // 4
+        with torch.cuda.device(dev):
+            cs = torch.cuda.current_stream(dev).cuda_stream
+            words = raw.data_ptr() + 4 * pos
+            acc = torch.empty((ng,), dtype=torch.uint8, device=dev)
+            F.call("imgxf_np_accept", words, ng, acc.data_ptr(), cs)
+            rank = torch.cumsum(acc, 0, dtype=torch.int64)
+            table = np.zeros(len(live), dtype=[("begin", "<i8"), ("scale", "<f8")])
+            table["begin"], table["scale"] = [b for b, _ in live], [s for _, s in live]
+            reqs_d = torch.from_numpy(table.view(np.uint8).copy()).to(dev)
+            info = torch.tensor([-1, 0], dtype=torch.int64, device=dev)
+            risky = torch.empty((RISKY_CAP,), dtype=torch.int64, device=dev)
+            xr = torch.zeros((2 + 2 * RISKY_CAP,), dtype=torch.float64, device=dev)
+            F.call("imgxf_np_normals_f32", words, ng, rank.data_ptr(), groups, n2, lead, reqs_d.data_ptr(), len(live), MARGIN, out.data_ptr(),
+                   info.data_ptr(), risky.data_ptr(), RISKY_CAP, xr.data_ptr(), cs)
+            last, nrisky = info.cpu().tolist()
+        if last < 0:
+            raise ValueError("too few accepted groups inside the margin")
+        if nrisky > RISKY_CAP:
+            raise ValueError("more samples near a float32 rounding boundary than the list holds")
+        if nrisky:
+            e = risky[:nrisky].cpu().numpy()
+            xv = xr[2:2 + 2 * nrisky].cpu().numpy().reshape(-1, 2)
+            b_arr = np.array([b for b, _ in live]); s_arr = np.array([s for _, s in live])
+            which = np.searchsorted(b_arr, e + lead, side="right") - 1
+            fix = np.array([np.float32(0.0 + s_arr[k] * _host_gauss(float(x), float(r))) for k, (x, r) in zip(which, xv)], np.float32)
+            out[torch.from_numpy(e + lead).to(dev)] = torch.from_numpy(fix).to(dev)
+            patched = int(nrisky)
+        pos += 4 * (last + 1)
+        if n2 & 1:
+            x1, r2 = xr[:2].cpu().tolist()
+            has_gauss, cached = True, _host_gauss(x1, r2)
+        else:
+            has_gauss, cached = False, 0.0
+    else:
+        has_gauss, cached = False, 0.0
+    d.noise = [out[b:b + c] for b, c in zip(begins, counts)]
+    d.position, d.has_gauss, d.gauss, d.patched = pos, has_gauss, cached, patched
     return d
 
 

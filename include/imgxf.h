@@ -420,6 +420,20 @@ int imgxf_mt19937_jump(const uint32_t* base_key, uint32_t* out_keys, int n_out, 
 int imgxf_mt19937_stretches(const uint32_t* keys, uint32_t* out, int n_stretches, int64_t blocks_per_stretch, int64_t total_blocks,
                             void* stream);
 
+/* NumPy's legacy_gauss over the word stream of imgxf_mt19937_blocks / _stretches (numpy/random/src/legacy/legacy-distributions.c
+ * restated; imagetransformations_amd/numpy_stream.py): group g = four consecutive words -> (x1, x2, r2), accepted iff 0 < r2 < 1.
+ * imgxf_np_accept writes the acceptance flags; with their inclusive prefix sum `rank`, imgxf_np_normals_f32 writes the float32
+ * results of consecutive np.random.normal(0, scale, count) calls: accepted group k <= groups yields normals 2 (k - 1), 2 (k - 1) + 1
+ * (f x2 then f x1) of n2; out[e + lead] = float(0.0 + scale * f x) with the scale of the request whose range (reqs: {int64 begin,
+ * double scale} sorted by begin, positions counted with `lead` = 1 if a cached normal precedes) holds it.  Samples within `margin`
+ * (relative) of a float32 rounding boundary are listed in risky[] (info[1] = how many; the host recomputes them with its libm);
+ * info[0] = the index of the groups-th accepted group, xr[0 .. 1] = its (x1, r2), xr[2 + 2 s ..] = (x, r2) of risky sample s
+ * (xr holds 2 + 2 risky_cap doubles). */
+int imgxf_np_accept(const uint32_t* words, int64_t ngroups, uint8_t* acc, void* stream);
+int imgxf_np_normals_f32(const uint32_t* words, int64_t ngroups, const int64_t* rank, int64_t groups, int64_t n2, int lead,
+                         const void* reqs, int nreq, double margin, float* out, int64_t* info, int64_t* risky, int64_t risky_cap,
+                         double* xr, void* stream);
+
 /* Why a file is outside the reader's class, or damaged (status[] of imgxf_jpeg_layout_host; 0 = accepted). */
 enum { IMGXF_JPEG_E_NOT_JPEG = 1,    /* no SOI */
        IMGXF_JPEG_E_MARKERS = 2,     /* damaged marker structure (also: SOS before SOF) */
