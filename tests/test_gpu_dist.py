@@ -78,11 +78,14 @@ def test_bench_distributed_branch_world1_nccl(device):
 def test_bench_two_rank_rehearsal_with_scatter_gather_children(device):
     """World size 2 on one GPU: gloo collectives, both ranks (and their scatter/gather children)
     share device 0 — the N > 1 control flow of bench.py end to end."""
-    port = _free_port()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "4", "--steps", "2", "--warmup", "1",
-           "--no-extras", "--no-1080p", "--sg-timeout", "240"]
-    res = subprocess.run(cmd, env=_env(port, IMGXF_BENCH_BACKEND="gloo", IMGXF_BENCH_SHARED_GPU="1"), capture_output=True, text=True, timeout=900)
+    for attempt in range(2):                              # (the rendezvous port is picked before the launcher binds it: one more draw if it was taken)
+        port = _free_port()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "4", "--steps", "2", "--warmup", "1",
+               "--no-extras", "--no-1080p", "--sg-timeout", "240"]
+        res = subprocess.run(cmd, env=_env(port, IMGXF_BENCH_BACKEND="gloo", IMGXF_BENCH_SHARED_GPU="1"), capture_output=True, text=True, timeout=900)
+        if res.returncode == 0 or "EADDRINUSE" not in res.stderr:
+            break
     assert res.returncode == 0, res.stderr[-2000:]
     r = _bench_line(res.stdout)
     assert r["n_gpus"] == 2 and r["config"]["global_frames"] == 8 and r["scaling"] == "weak"
